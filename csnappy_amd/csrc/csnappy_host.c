@@ -1,0 +1,226 @@
+/*
+ * csnappy_host.c -- the six csnappy.h entry points, in plain C, over the batched HIP layer.
+ *
+ * This file is what a program linked against the reference's libcsnappy.so sees.  Every codec
+ * call is one H2D copy, one batch launch of the HIP kernels with nblocks = 1, and one D2H copy
+ * (a whole-buffer csnappy_compress still runs its 32 KiB fragments in parallel, one wave each).
+ * There is no CPU codec here: without a usable HIP device the compress calls abort() and the
+ * decompress calls return CSNAPPY_E_HIP_UNAVAILABLE.
+ *
+ * Only the two functions that are pure integer arithmetic on a handful of bytes
+ * (csnappy_max_compressed_length, csnappy_get_uncompressed_length) run on the host.
+ *
+ * Reference semantics kept (file:line into the reference tree):
+ *   - caller owns all buffers; working_memory is accepted and ignored        csnappy.h:46-72
+ *   - compress cannot fail and does not bound-check `output`                 cl_tester.c:120-165
+ *   - *dst_len is updated only on CSNAPPY_E_OK                               csnappy_decompress.c:385
+ *   - re-entrant: calls are serialised on one mutex-guarded device context
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/csnappy.h"
+#include "../../include/csnappy_hip.h"
+
+struct buf {
+	void *p;
+	size_t cap;
+};
+
+static struct {
+	pthread_mutex_t mu;
+	int ready; /* 0 = not tried, 1 = ok, -1 = no device */
+	hipStream_t stream;
+	struct buf in, out, ws, desc;
+} g = { PTHREAD_MUTEX_INITIALIZER, 0, 0, { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+
+static int ctx_init(void)
+{
+	if (g.ready)
+		return g.ready;
+	g.ready = -1;
+	if (csnappy_hip_device_count() <= 0)
+		return g.ready;
+	if (hipStreamCreate(&g.stream) != hipSuccess)
+		return g.ready;
+	g.ready = 1;
+	return g.ready;
+}
+
+static int grow(struct buf *b, size_t need)
+{
+	if (need == 0)
+		need = 256;
+	if (b->cap >= need)
+		return 0;
+	if (b->p)
+		hipFree(b->p);
+	b->p = NULL;
+	b->cap = 0;
+	need = (need + (need >> 2) + 4095) & ~(size_t)4095;
+	if (hipMalloc(&b->p, need) != hipSuccess)
+		return -1;
+	b->cap = need;
+	return 0;
+}
+
+static void die(const char *what)
+{
+	fprintf(stderr, "libcsnappy (HIP): %s: %s -- no CPU fallback exists\n", what,
+		csnappy_hip_last_error());
+	abort();
+}
+
+/* descriptor block on the device: in_off, out_off (u64), in_len, out_len/out_cap, status, produced */
+struct desc {
+	uint64_t in_off, out_off;
+	uint32_t in_len, out_len, out_cap;
+	int32_t status;
+	uint32_t produced, pad;
+};
+
+uint32_t csnappy_max_compressed_length(uint32_t source_len)
+{
+	return 32u + source_len + source_len / 6u;
+}
+
+int csnappy_get_uncompressed_length(const char *start, uint32_t n, uint32_t *result)
+{
+	uint32_t shift = 0, k = 0;
+	*result = 0;
+	for (;;) {
+		uint8_t c;
+		if (shift >= 32 || k == n)
+			return CSNAPPY_E_HEADER_BAD;
+		c = (uint8_t)start[k++];
+		*result |= (uint32_t)(c & 0x7f) << shift;
+		if (c < 128)
+			return (int)k;
+		shift += 7;
+	}
+}
+
+static uint32_t compress_on_device(const char *input, uint32_t n, char *output, int p, int mode)
+{
+	struct desc d;
+	size_t out_cap = 32 + (size_t)n + n / 6, ws_need;
+	char *dd;
+	int rc;
+
+	pthread_mutex_lock(&g.mu);
+	if (ctx_init() < 0)
+		die("no usable HIP device");
+	ws_need = csnappy_hip_compress_workspace_size(1, n);
+	if (grow(&g.in, (size_t)n + 64) || grow(&g.out, out_cap + 64) || grow(&g.ws, ws_need) ||
+	    grow(&g.desc, sizeof(d)))
+		die("hipMalloc failed");
+	memset(&d, 0, sizeof(d));
+	d.in_len = n;
+	dd = (char *)g.desc.p;
+	if (hipMemcpyAsync(g.desc.p, &d, sizeof(d), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+	    (n && hipMemcpyAsync(g.in.p, input, n, hipMemcpyHostToDevice, g.stream) != hipSuccess))
+		die("hipMemcpy H2D failed");
+	rc = csnappy_hip_compress_batch(g.in.p, (const uint64_t *)(dd + offsetof(struct desc, in_off)),
+					(const uint32_t *)(dd + offsetof(struct desc, in_len)), 1, n,
+					g.out.p, (const uint64_t *)(dd + offsetof(struct desc, out_off)),
+					(uint32_t *)(dd + offsetof(struct desc, out_len)), p, mode, g.ws.p,
+					g.ws.cap, g.stream);
+	if (rc)
+		die("csnappy_hip_compress_batch failed");
+	if (hipMemcpyAsync(&d, g.desc.p, sizeof(d), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+	    hipStreamSynchronize(g.stream) != hipSuccess)
+		die("compress kernels failed");
+	if (d.out_len &&
+	    hipMemcpy(output, g.out.p, d.out_len, hipMemcpyDeviceToHost) != hipSuccess)
+		die("hipMemcpy D2H failed");
+	pthread_mutex_unlock(&g.mu);
+	return d.out_len;
+}
+
+char *csnappy_compress_fragment(const char *input, const uint32_t input_length, char *output,
+				void *working_memory, const int workmem_bytes_power_of_two)
+{
+	(void)working_memory;
+	return output + compress_on_device(input, input_length, output, workmem_bytes_power_of_two,
+					   CSNAPPY_HIP_FRAGMENT);
+}
+
+void csnappy_compress(const char *input, uint32_t input_length, char *compressed,
+		      uint32_t *out_compressed_length, void *working_memory,
+		      const int workmem_bytes_power_of_two)
+{
+	(void)working_memory;
+	*out_compressed_length = compress_on_device(input, input_length, compressed,
+						    workmem_bytes_power_of_two, CSNAPPY_HIP_STREAM);
+}
+
+static int decompress_on_device(const char *src, uint32_t src_len, char *dst, uint32_t cap,
+				uint32_t alloc, uint32_t *produced, int mode)
+{
+	struct desc d;
+	char *dd;
+	int rc, status;
+
+	pthread_mutex_lock(&g.mu);
+	if (ctx_init() < 0) {
+		pthread_mutex_unlock(&g.mu);
+		return CSNAPPY_E_HIP_UNAVAILABLE;
+	}
+	if (grow(&g.in, (size_t)src_len + 64) || grow(&g.out, (size_t)alloc + 64) ||
+	    grow(&g.desc, sizeof(d))) {
+		pthread_mutex_unlock(&g.mu);
+		return CSNAPPY_E_HIP_UNAVAILABLE;
+	}
+	memset(&d, 0, sizeof(d));
+	d.in_len = src_len;
+	d.out_cap = cap;
+	dd = (char *)g.desc.p;
+	status = CSNAPPY_E_HIP_UNAVAILABLE;
+	if (hipMemcpyAsync(g.desc.p, &d, sizeof(d), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+	    (src_len && hipMemcpyAsync(g.in.p, src, src_len, hipMemcpyHostToDevice, g.stream) != hipSuccess))
+		goto out;
+	rc = csnappy_hip_decompress_batch(g.in.p, (const uint64_t *)(dd + offsetof(struct desc, in_off)),
+					  (const uint32_t *)(dd + offsetof(struct desc, in_len)), 1,
+					  g.out.p, (const uint64_t *)(dd + offsetof(struct desc, out_off)),
+					  (const uint32_t *)(dd + offsetof(struct desc, out_cap)),
+					  (int32_t *)(dd + offsetof(struct desc, status)),
+					  (uint32_t *)(dd + offsetof(struct desc, produced)), mode,
+					  g.stream);
+	if (rc)
+		goto out;
+	if (hipMemcpyAsync(&d, g.desc.p, sizeof(d), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+	    hipStreamSynchronize(g.stream) != hipSuccess)
+		goto out;
+	if (d.status == CSNAPPY_E_OK && d.produced &&
+	    hipMemcpy(dst, g.out.p, d.produced, hipMemcpyDeviceToHost) != hipSuccess)
+		goto out;
+	status = d.status;
+	*produced = d.produced;
+out:
+	pthread_mutex_unlock(&g.mu);
+	return status;
+}
+
+int csnappy_decompress(const char *src, uint32_t src_len, char *dst, uint32_t dst_len)
+{
+	uint32_t produced = 0, olen = 0, alloc = dst_len;
+	/* The kernel never writes past min(dst_len, header length): size the device buffer by the
+	 * header when it parses.  The kernel itself re-does every check of the reference. */
+	if (csnappy_get_uncompressed_length(src, src_len, &olen) > 0 && olen < alloc)
+		alloc = olen;
+	return decompress_on_device(src, src_len, dst, dst_len, alloc, &produced, CSNAPPY_HIP_STREAM);
+}
+
+int csnappy_decompress_noheader(const char *src, uint32_t src_len, char *dst, uint32_t *dst_len)
+{
+	uint32_t produced = 0;
+	int rc = decompress_on_device(src, src_len, dst, *dst_len, *dst_len, &produced,
+				      CSNAPPY_HIP_FRAGMENT);
+	if (rc == CSNAPPY_E_OK)
+		*dst_len = produced;
+	return rc;
+}

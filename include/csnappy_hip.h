@@ -1,0 +1,104 @@
+/*
+ * csnappy_hip.h -- the batched C-ABI the HIP kernels sit behind.
+ *
+ * The reference's API hands the codec one caller-owned buffer per synchronous call
+ * (csnappy.h:46-72, 99-119).  One <=64 KiB call cannot feed a GPU, so next to the six legacy
+ * symbols (include/csnappy.h) the library exports a batch form of the same four operations:
+ *
+ *   reference call                                   batch mode            this header
+ *   csnappy_compress            (csnappy.h:65-72)    CSNAPPY_HIP_STREAM    csnappy_hip_compress_batch
+ *   csnappy_compress_fragment   (csnappy.h:46-52)    CSNAPPY_HIP_FRAGMENT  csnappy_hip_compress_batch
+ *   csnappy_decompress          (csnappy.h:99-104)   CSNAPPY_HIP_STREAM    csnappy_hip_decompress_batch
+ *   csnappy_decompress_noheader (csnappy.h:114-119)  CSNAPPY_HIP_FRAGMENT  csnappy_hip_decompress_batch
+ *
+ * Block b of a batch is exactly one reference call on (in + in_off[b], in_len[b]) writing to
+ * (out + out_off[b]); results (bytes, lengths, status codes) are identical to the reference's.
+ * Plain pointers and sizes only.  All data pointers are DEVICE pointers (hipMalloc'ed, or
+ * torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Calls enqueue work and return; they do not synchronise.  Return value: 0, or a
+ * negative CSNAPPY_HIP_E_* code when the launch itself could not be made.
+ */
+#ifndef CSNAPPY_AMD_CSNAPPY_HIP_H_
+#define CSNAPPY_AMD_CSNAPPY_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSNAPPY_HIP_STREAM 0   /* varint length prefix + 32 KiB fragments (csnappy_compress.c:621-656) */
+#define CSNAPPY_HIP_FRAGMENT 1 /* one raw fragment <= 32 KiB, no prefix (csnappy_compress.c:469-606) */
+
+#define CSNAPPY_HIP_E_ARG (-101)     /* bad argument (p outside 9..16, FRAGMENT block > 32 KiB, ...) */
+#define CSNAPPY_HIP_E_RUNTIME (-102) /* a HIP runtime call failed; see csnappy_hip_last_error() */
+#define CSNAPPY_HIP_E_WORKSPACE (-103) /* workspace smaller than csnappy_hip_compress_workspace_size() */
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int csnappy_hip_device_count(void);
+
+/* Text of the last HIP runtime error seen by this library on the calling thread. */
+const char *csnappy_hip_last_error(void);
+
+/*
+ * Device scratch needed by csnappy_hip_compress_batch for `nblocks` blocks whose lengths are
+ * all <= max_in_len.  (Per-fragment staging slots for the 2nd.. fragments of each block and the
+ * per-fragment length table; 256-byte aligned base required.)
+ */
+size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len);
+
+/*
+ * Compress nblocks independent blocks.
+ *   d_in, d_in_off[b], d_in_len[b]   input bytes of block b            (in_len[b] <= max_in_len)
+ *   d_out, d_out_off[b]              start of block b's output slot, which must hold
+ *                                    csnappy_max_compressed_length(in_len[b]) bytes (unchecked,
+ *                                    as in the reference)
+ *   d_out_len[b]                     receives the compressed size of block b
+ *   p                                workmem_bytes_power_of_two, 9..16 (changes the bytes)
+ *   mode                             CSNAPPY_HIP_STREAM | CSNAPPY_HIP_FRAGMENT
+ */
+int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+			       uint32_t nblocks, uint32_t max_in_len, void *d_out,
+			       const uint64_t *d_out_off, uint32_t *d_out_len, int p, int mode,
+			       void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Decompress nblocks independent blocks.
+ *   d_out_cap[b]    STREAM: dst_len of csnappy_decompress; FRAGMENT: *dst_len on entry of
+ *                   csnappy_decompress_noheader
+ *   d_status[b]     CSNAPPY_E_* code the reference call would return (0, -1, -2, -3, -5)
+ *   d_produced[b]   bytes produced when status is 0 (FRAGMENT: *dst_len on exit), else 0
+ * Bytes of the output slot beyond `produced` are never written.
+ */
+int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
+				 const uint32_t *d_in_len, uint32_t nblocks, void *d_out,
+				 const uint64_t *d_out_off, const uint32_t *d_out_cap,
+				 int32_t *d_status, uint32_t *d_produced, int mode, void *stream);
+
+/*
+ * Per-kernel timing for bench.py: when enabled, the batch calls bracket each kernel with
+ * hipEvents on `stream`, synchronise the stream before returning, and remember the durations.
+ * slots: [0] compress_fragments  [1] stitch_blocks  [2] decompress_blocks  (milliseconds of the
+ * most recent call; 0 when that kernel did not run).
+ */
+void csnappy_hip_set_kernel_timing(int enable);
+void csnappy_hip_get_kernel_timing(float ms[4]);
+
+/*
+ * Synthetic workloads of SURVEY.md section 8(d) (not part of the reference; bench/test input).
+ * kind: 0 = G_text (URL-like tokens), 1 = G_low (runs / short periods), 2 = G_page (zram-style
+ * page mix: zero / heap words / text / random).  Block i is a pure function of (kind, seed, i,
+ * block_len), so any range can be generated on any rank.  The _host form fills host memory with
+ * the same bytes (used by the CPU tests and the CPU baseline).
+ */
+int csnappy_hip_workload_generate(int kind, uint64_t seed, uint64_t first_block, uint32_t nblocks,
+				  uint32_t block_len, void *d_out, void *stream);
+void csnappy_workload_generate_host(int kind, uint64_t seed, uint64_t first_block,
+				    uint32_t nblocks, uint32_t block_len, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CSNAPPY_AMD_CSNAPPY_HIP_H_ */

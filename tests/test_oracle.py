@@ -1,0 +1,248 @@
+"""CPU tests that PIN THE ORACLE: the restatement in oracle/snappy_oracle.c must agree with
+(1) the reference's own fixtures, (2) golden vectors generated from the compiled reference
+(tests/golden/make_golden.py), (3) the compiled reference itself when oracle/_ref is present,
+and the wave-step model of the compress kernel must agree with the oracle."""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from csnappy_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def port():
+    return oracle.Port()
+
+
+def codecs():
+    out = [oracle.Port()]
+    if oracle.have_ref():
+        out.append(oracle.Ref())
+    return out
+
+
+# ---- reference fixtures -----------------------------------------------------------------------
+def test_shipped_golden_stream_is_p15(port, urls, golden_dir):
+    """reference testdata/urls.10K.snappy == csnappy_compress(urls.10K, p=15)."""
+    shipped = open(os.path.join(golden_dir, "urls.10K.snappy"), "rb").read()
+    assert sha(urls) == GOLD["urls_sha256"]
+    assert port.compress(urls, 15) == shipped
+    rc, out = port.decompress(shipped, len(urls))
+    assert rc == 0 and out == urls
+
+
+@pytest.mark.parametrize("p", range(9, 17))
+def test_urls_whole_file_every_table_power(port, urls, p):
+    c = port.compress(urls, p)
+    assert len(c) == GOLD["urls_whole"][str(p)]["size"]
+    assert sha(c) == GOLD["urls_whole"][str(p)]["sha256"]
+    rc, out = port.decompress(c, len(urls))
+    assert rc == 0 and out == urls
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["urls_blocks"]))
+def test_urls_block_modes(port, urls, name):
+    g = GOLD["urls_blocks"][name]
+    outs = port.compress_blocks(urls, g["block"], g["p"], g["mode"])
+    assert [len(o) for o in outs] == g["lens"]
+    assert sha(b"".join(outs)) == g["sha256"]
+
+
+def test_unaligned_uint64_torture_stream(port, golden_dir):
+    """reference Makefile:37-55: 2409 self-overlapping copies, 532 with offset < 8."""
+    s = gzip.open(os.path.join(golden_dir, "unaligned_uint64_test.snappy.gz")).read()
+    b = gzip.open(os.path.join(golden_dir, "unaligned_uint64_test.bin.gz")).read()
+    assert sha(s) == GOLD["unaligned"]["snappy_sha256"] and sha(b) == GOLD["unaligned"]["bin_sha256"]
+    rc, out = port.decompress(s, len(b))
+    assert rc == 0 and out == b
+
+
+def test_baddata3_fails_cleanly(port, golden_dir):
+    bad = open(os.path.join(golden_dir, "baddata3.snappy"), "rb").read()
+    rc, n = port.get_uncompressed_length(bad)
+    assert [rc, n] == GOLD["baddata3"]["get_len"]
+    assert port.decompress(bad, n)[0] == GOLD["baddata3"]["decompress"] == -5
+    assert port.decompress_noheader(bad[rc:], n)[0] == GOLD["baddata3"]["noheader"]
+
+
+# ---- golden vectors from the compiled reference -----------------------------------------------
+def test_kats(port):
+    from golden.make_golden import kat_inputs
+    for name, data in kat_inputs().items():
+        g = GOLD["kats"][name]
+        assert len(data) == g["n"]
+        if g["p15"] is not None:
+            assert port.compress(data, 15).hex() == g["p15"], name
+        for p in (9, 15, 16):
+            assert sha(port.compress(data, p)) == g[f"p{p}_sha256"], (name, p)
+
+
+def test_max_compressed_length(port):
+    for n, want in GOLD["max_compressed_length"].items():
+        assert port.max_compressed_length(int(n)) == want
+        assert oracle.max_compressed_length(int(n)) == want
+
+
+@pytest.mark.parametrize("e", GOLD["negative"], ids=lambda e: e["hex"] or "empty")
+def test_negative_vectors(port, e):
+    raw = bytes.fromhex(e["hex"])
+    rc, val = port.get_uncompressed_length(raw)
+    assert rc == e["get_len"][0]
+    if rc > 0:
+        assert val == e["get_len"][1]
+    assert port.decompress(raw, e["dst_len"])[0] == e["decompress"]
+    if "noheader" in e:
+        rc_nh, produced, body = port.decompress_noheader(raw[rc:], e["dst_len"])
+        assert rc_nh == e["noheader"][0]
+        if rc_nh == 0:
+            assert produced == e["noheader"][1] and body.hex() == e["noheader"][2]
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["workloads"]))
+def test_workload_generators_and_reference_outputs(port, name):
+    g = GOLD["workloads"][name]
+    data = api.generate_host(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
+    assert sha(data) == g["input_sha256"], "workload generator changed (recipes are frozen)"
+    outs = port.compress_blocks(data, g["block"], g["p"], g["mode"])
+    assert [len(o) for o in outs] == g["lens"]
+    assert sha(b"".join(outs)) == g["sha256"]
+    # any block range is reproducible independently (what the multi-GPU sharding relies on)
+    part = api.generate_host(g["kind"], g["seed"], 5, 3, g["block"])
+    assert np.array_equal(part, data[5 * g["block"]:8 * g["block"]])
+
+
+# ---- the port against the compiled reference, fuzzed ------------------------------------------
+def _fuzz_inputs(seed, count, max_n):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        n = int(rng.choice([rng.integers(0, 70), rng.integers(0, max_n), rng.integers(32760, 32780),
+                            rng.integers(65530, 65545)]))
+        n = min(n, max_n)
+        alpha = int(rng.choice([1, 2, 3, 4, 16, 256]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            x = rng.integers(0, alpha, n, dtype=np.uint8)
+        elif kind == 1:
+            x = np.resize(rng.integers(0, alpha, int(rng.integers(1, 40)), dtype=np.uint8), n)
+        else:
+            x = rng.integers(0, alpha, n, dtype=np.uint8)
+            for _ in range(5):
+                if n > 100:
+                    s = int(rng.integers(0, n - 50))
+                    ln = int(rng.integers(4, min(3000, n - s)))
+                    d = int(rng.integers(0, n - ln))
+                    x[d:d + ln] = x[s:s + ln].copy()
+        yield x, int(rng.integers(9, 17))
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_port_equals_compiled_reference_fuzz():
+    P, R = oracle.Port(), oracle.Ref()
+    for x, p in _fuzz_inputs(1, 600, 70000):
+        a, b = P.compress(x, p), R.compress(x, p)
+        assert a == b, (len(x), p)
+        if len(x) <= 32768:
+            assert P.compress_fragment(x, p) == R.compress_fragment(x, p)
+        rc, out = P.decompress(a, len(x))
+        assert rc == 0 and out == x.tobytes()
+        rc2, out2 = R.decompress(a, len(x))
+        assert rc2 == 0 and out2 == out
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_port_equals_compiled_reference_on_corrupted_streams():
+    """Mutate valid streams; status codes (and output on success) must agree.  Streams whose tag
+    header bytes are cut off by the end of input are excluded: the reference reads stale stack
+    bytes there, so its result is undefined."""
+    P, R = oracle.Port(), oracle.Ref()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for x, p in _fuzz_inputs(2, 300, 6000):
+        c = bytearray(P.compress(x, p))
+        if len(c) < 4:
+            continue
+        for _ in range(4):
+            m = bytearray(c)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            cut = int(rng.integers(0, 3))
+            if cut and len(m) > cut:
+                m = m[:-cut]
+            cap = int(rng.choice([len(x), len(x) + 7, max(len(x) - 3, 0), 2 * len(x) + 64]))
+            if _has_truncated_tag(bytes(m)):
+                continue
+            ra, oa = P.decompress(bytes(m), cap)
+            rb, ob = R.decompress(bytes(m), cap)
+            assert ra == rb, (bytes(m).hex()[:80], cap)
+            if ra == 0:
+                n = P.get_uncompressed_length(bytes(m))
+                rn, prod, body = P.decompress_noheader(bytes(m)[n[0]:], cap)
+                rn2, prod2, body2 = R.decompress_noheader(bytes(m)[n[0]:], cap)
+                assert (rn, prod, body) == (rn2, prod2, body2)
+            checked += 1
+    assert checked > 500
+
+
+def _has_truncated_tag(stream):
+    """True if walking the tags hits a tag whose extra bytes run past the end of input."""
+    P = oracle.Port()
+    rc, _ = P.get_uncompressed_length(stream)
+    if rc < 0:
+        return False
+    i, n = rc, len(stream)
+    while i < n:
+        t = stream[i]
+        k = t & 3
+        if k == 0:
+            ln = (t >> 2) + 1
+            ex = ln - 60 if ln > 60 else 0
+            if i + 1 + ex > n:
+                return True
+            if ex:
+                ln = int.from_bytes(stream[i + 1:i + 1 + ex], "little") + 1
+            i += 1 + ex + ln
+        else:
+            ex = (1, 2, 4)[k - 1]
+            if i + 1 + ex > n:
+                return True
+            i += 1 + ex
+    return False
+
+
+# ---- the wave-step algorithm of the HIP compress kernel ---------------------------------------
+def test_wave_step_model_is_bit_exact(port, urls):
+    import wave_model as wm
+    frag = urls[100000:100000 + 32768]
+    for p in (16, 13):
+        assert wm.compress_fragment(frag, p) == port.compress_fragment(frag, p)
+    for x, p in _fuzz_inputs(3, 120, 6000):
+        x = x[:32768]
+        for s_entries in (4, min(1 << (p - 1), 2048)):
+            assert wm.compress_fragment(x.tobytes(), p, s_entries) == port.compress_fragment(x, p), \
+                (len(x), p, s_entries)
+
+
+# ---- batch drivers used by the GPU parity tests and the CPU baseline --------------------------
+def test_batch_drivers_match_single_calls(port, urls):
+    b = api.Batch.uniform(len(urls), 65536, device=None)
+    out, out_len = oracle.batch_compress(port, urls, b.in_off, b.in_len, b.out_off, b.out_bytes, 16,
+                                         oracle.STREAM, threads=4)
+    g = GOLD["urls_blocks"]["64k_p16"]
+    assert out_len.tolist() == g["lens"]
+    cat = b"".join(bytes(out[int(o):int(o) + int(n)]) for o, n in zip(b.out_off, out_len))
+    assert sha(cat) == g["sha256"]
+    back, status, _ = oracle.batch_decompress(port, out, b.out_off, out_len, b.in_off, b.in_len,
+                                              b.in_bytes, oracle.STREAM, threads=4)
+    assert (status == 0).all() and bytes(back) == urls

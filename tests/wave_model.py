@@ -1,0 +1,135 @@
+"""Lane-level model of the compress kernel's step logic (TEST INFRASTRUCTURE).
+
+`snappy_compress_fragments` (csnappy_amd/csrc/csnappy_kernels.hip) evaluates 64 probe positions
+of the reference's sequential probe loop per step and truncates the step at the first lane that
+shares a hash slot with an earlier lane.  This file restates exactly that step logic in plain
+Python, lane by lane, so the claim "the wave-step algorithm is bit-identical to the sequential
+loop of csnappy_compress.c:469-606" can be fuzzed against the oracle on the CPU, where there is
+no GPU.  It models the ALGORITHM (roles, conflict truncation, state update, record queue,
+EmitCopy chunking); the HIP code is a SIMT transcription of it.
+"""
+import struct
+
+FRAG = 32768
+MARGIN = 15
+KMUL = 0x1E35A7BD
+WAVE = 64
+
+
+def scan_pos(s, i):
+    a, b = i >> 5, i & 31
+    return s + 16 * a * (a + 1) + b * (a + 1)
+
+
+def plan_copy(length, off):
+    k64 = k60 = 0
+    if length >= 68:
+        k64 = (length - 68) // 64 + 1
+        length -= 64 * k64
+    if length > 64:
+        k60 = 1
+        length -= 60
+    return k64, k60, length, 3 * (k64 + k60) + (2 if (length < 12 and off < 2048) else 3)
+
+
+def encode_records(F, records):
+    out = bytearray()
+    for lit_start, lit_len, coff, clen in records:
+        if lit_len:
+            n = lit_len - 1
+            if lit_len <= 60:
+                out.append(n << 2)
+            elif lit_len <= 256:
+                out += bytes([60 << 2, n])
+            else:
+                out += bytes([61 << 2, n & 0xFF, n >> 8])
+            out += F[lit_start:lit_start + lit_len]
+        if clen:
+            k64, k60, last, _ = plan_copy(clen, coff)
+            lo, hi = coff & 0xFF, coff >> 8
+            out += bytes([0xFE, lo, hi]) * k64
+            out += bytes([0xEE, lo, hi]) * k60
+            if last < 12 and coff < 2048:
+                out += bytes([1 + ((last - 4) << 2) + ((coff >> 8) << 5), lo])
+            else:
+                out += bytes([2 + ((last - 1) << 2), lo, hi])
+    return bytes(out)
+
+
+def compress_fragment(F, p, s_entries=None, stats=None):
+    """Wave-step model. F: bytes (<= 32768). Returns compressed bytes."""
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 32
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    if s_entries is None:
+        s_entries = min(1 << (p - 1), 2048)
+    smask = s_entries - 1
+    records = []
+    next_emit = 0
+    if n >= MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        ip, spec, s, qi = 0, 0, 1, 0
+        while True:
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            pos, valid, probing = [0] * WAVE, [False] * WAVE, [True] * WAVE
+            for lane in range(WAVE):
+                if lane < spec:
+                    k = lane + (2 - spec)
+                    pos[lane] = ip - 1 + k
+                    valid[lane] = True
+                    probing[lane] = k == 1
+                else:
+                    i = qi + lane - spec
+                    pos[lane] = scan_pos(s, i)
+                    valid[lane] = scan_pos(s, i + 1) <= ip_limit
+                    if not valid[lane]:
+                        pos[lane] = 0
+            w = [rd32(pos[l]) for l in range(WAVE)]
+            h = [((w[l] * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            key = [h[l] & smask for l in range(WAVE)]
+            first = {}
+            for l in range(WAVE):
+                if valid[l] and key[l] not in first:
+                    first[key[l]] = l
+            cand = [tab[h[l]] for l in range(WAVE)]
+            cw = [rd32(cand[l]) for l in range(WAVE)]
+            c = next((l for l in range(WAVE) if valid[l] and first[key[l]] < l), 64)
+            v = next((l for l in range(WAVE) if not valid[l]), 64)
+            ulim = min(c, v)
+            m = next((l for l in range(ulim) if probing[l] and cw[l] == w[l]), None)
+            if m is None:
+                for l in range(ulim):
+                    tab[h[l]] = pos[l]
+                if ulim == v and v < 64:
+                    break
+                if ulim < spec:
+                    spec -= ulim
+                    s, qi = ip + 1, 0
+                else:
+                    if spec:
+                        s, qi = ip + 1, 0
+                    qi += ulim - spec
+                    spec = 0
+                continue
+            for l in range(m + 1):
+                tab[h[l]] = pos[l]
+            base, cnd = pos[m], cand[m]
+            ma, mb = cnd + 4, base + 4
+            L = n - mb
+            k = 0
+            while k < L and F[ma + k] == F[mb + k]:
+                k += 1
+            matched = 4 + k
+            records.append((next_emit, base - next_emit, base - cnd, matched))
+            ip = base + matched
+            next_emit = ip
+            if ip >= ip_limit:
+                break
+            spec, s, qi = 2, ip + 1, 0
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
