@@ -43,6 +43,14 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (there is no CPU fallback for the codec)")
+    # ONE HIP runtime per process: the torch wheel bundles its own libamdhip64.so (SONAME
+    # libamdhip64.so.7).  Import torch first so the dynamic linker binds our NEEDED
+    # libamdhip64.so.7 to that already-loaded copy; loading /opt/rocm's copy beside it gives two
+    # runtimes and the second one to initialise reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.csnappy_max_compressed_length.restype = u32

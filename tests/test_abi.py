@@ -1,0 +1,93 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol the two headers declare, and the host-arithmetic entry points behave like the
+reference's.  No compute calls are made here (those are the -m gpu tests)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from csnappy_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(csnappy_\w+)\s*\(", text)))
+
+
+def test_headers_declare_what_the_binding_lists():
+    assert declared("csnappy.h") == sorted(api.LEGACY_SYMBOLS)
+    assert declared("csnappy_hip.h") == sorted(api.HIP_SYMBOLS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = api.lib()
+    for name in api.LEGACY_SYMBOLS + api.HIP_SYMBOLS:
+        assert hasattr(L, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(api.LEGACY_SYMBOLS + api.HIP_SYMBOLS) <= exported
+    # the code object for gfx950 is embedded
+    blob = open(api.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_reference_header_compiles_against_our_header_as_c():
+    """A C translation unit written against the reference's csnappy.h compiles against ours."""
+    src = r"""
+    #include "csnappy.h"
+    #if CSNAPPY_VERSION != 5 || CSNAPPY_WORKMEM_BYTES != 65536 || CSNAPPY_E_DATA_MALFORMED != -5
+    #error macros differ
+    #endif
+    uint32_t (*a)(uint32_t) = csnappy_max_compressed_length;
+    char *(*b)(const char *, const uint32_t, char *, void *, const int) = csnappy_compress_fragment;
+    void (*c)(const char *, uint32_t, char *, uint32_t *, void *, const int) = csnappy_compress;
+    int (*d)(const char *, uint32_t, uint32_t *) = csnappy_get_uncompressed_length;
+    int (*e)(const char *, uint32_t, char *, uint32_t) = csnappy_decompress;
+    int (*f)(const char *, uint32_t, char *, uint32_t *) = csnappy_decompress_noheader;
+    int main(void) { return a && b && c && d && e && f ? 0 : 1; }
+    """
+    subprocess.run(["gcc", "-std=gnu89", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I",
+                    os.path.join(ROOT, "include"), "-"], input=src, text=True, check=True)
+
+
+def test_host_arithmetic_entry_points():
+    # csnappy_compress.c:612-616 incl. the uint32 wrap
+    for n, want in ((0, 32), (1, 33), (4096, 4810), (32768, 38261), (65536, 76490), (0xFFFFFFFF, 715827913)):
+        assert api.max_compressed_length(n) == want
+    # csnappy_decompress.c:45-71
+    assert api.get_uncompressed_length(b"") [0] == -1
+    assert api.get_uncompressed_length(bytes.fromhex("ffffffffff01"))[0] == -1
+    assert api.get_uncompressed_length(bytes.fromhex("ffffffff7f")) == (5, 0xFFFFFFFF)
+    assert api.get_uncompressed_length(bytes.fromhex("80"))[0] == -1
+    assert api.get_uncompressed_length(bytes.fromhex("808004")) == (3, 65536)
+    assert api.get_uncompressed_length(bytes.fromhex("87ed2a")) == (3, 702087)
+
+
+def test_no_cpu_fallback_without_a_device():
+    if api.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError):
+        api.compress(b"abc")
+    # the C entry point itself reports the missing device instead of decoding on the host
+    L = api.lib()
+    src = np.frombuffer(bytes.fromhex("0308616263"), dtype=np.uint8)
+    dst = np.zeros(8, np.uint8)
+    assert L.csnappy_decompress(src.ctypes.data, 5, dst.ctypes.data, 8) == api.E_HIP_UNAVAILABLE
+    assert not dst.any()
+    assert L.csnappy_hip_compress_workspace_size(16384, 65536) >= 16384 * 38261
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under csnappy_amd/, include/ or tools/ may reference oracle/."""
+    for base in ("csnappy_amd", "include", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".c", ".h", ".hip", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle" not in text.replace("no CPU", ""), os.path.join(dirpath, f)

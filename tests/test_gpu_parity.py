@@ -1,0 +1,365 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libcsnappy.so), against the
+oracle on the same inputs.  Bit-exact: compressed bytes, compressed lengths, decompressed
+bytes, status codes.  The checker is the compiled reference (oracle/_ref) when its .so
+travelled with the repo, else the restatement that test_oracle.py pins to it."""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from csnappy_amd import api
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    api.require_device()  # fail loudly: these tests must never pass on a fallback
+    torch.cuda.set_device(0)
+    return torch
+
+
+@pytest.fixture(scope="module")
+def chk():
+    return oracle.best()
+
+
+# -------------------------------------------------------------------------------------------------
+# helpers
+# -------------------------------------------------------------------------------------------------
+def gpu_compress(torch, host, lens, p, mode):
+    """-> (list of per-block compressed bytes, Batch, device output tensor)"""
+    b = api.Batch(lens)
+    d_in = torch.from_numpy(np.array(host, dtype=np.uint8, copy=True)).cuda() if len(host) else \
+        torch.zeros(16, dtype=torch.uint8, device="cuda")
+    # poison the output so unwritten bytes are visible
+    d_out = torch.full((b.out_bytes + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    b.d_out_len.fill_(-1)
+    api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len,
+                       p, mode, b.d_ws)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    out_len = b.d_out_len.cpu().numpy().astype(np.uint32)
+    blocks = [bytes(out[int(o):int(o) + int(n)]) for o, n in zip(b.out_off, out_len)]
+    # nothing may be written past the slot (reference contract: slot = max_compressed_length)
+    assert (out[b.out_bytes:] == 0xA5).all()
+    return blocks, b, d_out
+
+
+def gpu_decompress(torch, streams, caps, mode, out_slot=None):
+    """streams: list of bytes; caps: list of dst_len.  -> (status[], produced[], outputs[])"""
+    n = len(streams)
+    lens = np.array([len(s) for s in streams], dtype=np.uint32)
+    in_off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    blob = np.frombuffer(b"".join(streams) + b"\0" * 16, dtype=np.uint8).copy()
+    caps = np.asarray(caps, dtype=np.uint32)
+    slot = caps.astype(np.uint64) + 64 if out_slot is None else np.asarray(out_slot, dtype=np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(slot[:-1], dtype=np.uint64)]).astype(np.uint64)
+    total = int(slot.sum())
+    t = lambda a, dt: torch.from_numpy(a.astype(dt)).cuda()
+    d_in = torch.from_numpy(blob).cuda()
+    d_out = torch.full((total + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    status = torch.full((n,), -99, dtype=torch.int32, device="cuda")
+    produced = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    api.decompress_batch(d_in, t(in_off, np.int64), t(lens, np.int32), d_out, t(out_off, np.int64),
+                         t(caps, np.int32), status, produced, mode)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    st, pr = status.cpu().numpy(), produced.cpu().numpy().astype(np.uint32)
+    outs = []
+    for i in range(n):
+        o = int(out_off[i])
+        outs.append(bytes(out[o:o + int(pr[i])]))
+        # on success nothing past `produced` is written; on failure (like the reference, which
+        # has written part of the output by then) nothing past dst_len
+        keep = int(pr[i]) if st[i] == 0 else min(int(caps[i]), int(slot[i]))
+        assert (out[o + keep:o + int(slot[i])] == 0x5A).all(), f"block {i}: wrote past its limit"
+    return st, pr, outs
+
+
+def oracle_blocks(chk, host, lens, p, mode):
+    outs, s = [], 0
+    for n in lens:
+        chunk = host[s:s + n]
+        outs.append(chk.compress(chunk, p) if mode == api.STREAM else chk.compress_fragment(chunk, p))
+        s += n
+    return outs
+
+
+# -------------------------------------------------------------------------------------------------
+# compress
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(GOLD["urls_blocks"]))
+def test_urls_blocks_match_reference_goldens(torch, urls, name):
+    g = GOLD["urls_blocks"][name]
+    data = np.frombuffer(urls, dtype=np.uint8)
+    lens = api.Batch.uniform(len(urls), g["block"], device=None).in_len
+    blocks, _, _ = gpu_compress(torch, data, lens, g["p"], g["mode"])
+    assert [len(b) for b in blocks] == g["lens"]
+    assert sha(b"".join(blocks)) == g["sha256"]
+
+
+@pytest.mark.parametrize("p", range(9, 17))
+def test_urls_whole_file_one_stream(torch, urls, p):
+    """702087-byte stream = 22 fragments compressed in parallel + stitched; p=15 equals the
+    reference's shipped testdata/urls.10K.snappy, p=16 equals what its cl_tester emits."""
+    data = np.frombuffer(urls, dtype=np.uint8)
+    blocks, _, _ = gpu_compress(torch, data, [len(urls)], p, api.STREAM)
+    assert len(blocks[0]) == GOLD["urls_whole"][str(p)]["size"]
+    assert sha(blocks[0]) == GOLD["urls_whole"][str(p)]["sha256"]
+
+
+def test_kats_via_legacy_api(torch, chk):
+    from golden.make_golden import kat_inputs
+    for name, data in kat_inputs().items():
+        g = GOLD["kats"][name]
+        for p in (9, 15, 16):
+            assert sha(api.compress(data, p)) == g[f"p{p}_sha256"], (name, p)
+        if len(data) <= 32768:
+            assert api.compress_fragment(data, 15) == chk.compress_fragment(data, 15), name
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["workloads"]))
+def test_synthetic_workloads_device_generator_and_compress(torch, name):
+    g = GOLD["workloads"][name]
+    d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
+    torch.cuda.synchronize()
+    host = d_in.cpu().numpy()
+    assert sha(host) == g["input_sha256"], "device generator differs from the frozen host recipe"
+    blocks, _, _ = gpu_compress(torch, host, [g["block"]] * g["nblocks"], g["p"], g["mode"])
+    assert [len(b) for b in blocks] == g["lens"]
+    assert sha(b"".join(blocks)) == g["sha256"]
+
+
+def _ragged_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        n = int(rng.choice([0, 1, 14, 15, 16, 17, rng.integers(0, 300), rng.integers(0, 9000),
+                            rng.integers(32750, 32790), rng.integers(65500, 65560),
+                            rng.integers(0, 140000)]))
+        alpha = int(rng.choice([1, 2, 4, 16, 256]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            x = rng.integers(0, alpha, n, dtype=np.uint8)
+        elif kind == 1:
+            x = np.resize(rng.integers(0, alpha, int(rng.integers(1, 70)), dtype=np.uint8), n)
+        else:
+            x = rng.integers(0, alpha, n, dtype=np.uint8)
+            for _ in range(6):
+                if n > 100:
+                    s = int(rng.integers(0, n - 50))
+                    ln = int(rng.integers(4, min(5000, n - s)))
+                    d = int(rng.integers(0, n - ln))
+                    x[d:d + ln] = x[s:s + ln].copy()
+        yield x
+
+
+@pytest.mark.parametrize("p", [9, 10, 12, 13, 14, 15, 16])
+def test_ragged_stream_batch_fuzz(torch, chk, p):
+    """Empty, tiny, fragment-boundary and multi-fragment blocks in one batch, arbitrary input
+    alignment (blocks are laid end to end, so most start at odd addresses)."""
+    xs = list(_ragged_cases(100 + p, 48))
+    host = np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+    lens = [len(x) for x in xs]
+    blocks, _, _ = gpu_compress(torch, host, lens, p, api.STREAM)
+    want = oracle_blocks(chk, host, lens, p, api.STREAM)
+    for i, (a, b) in enumerate(zip(blocks, want)):
+        assert a == b, f"p={p} block {i} (n={lens[i]}): {len(a)} vs {len(b)} bytes"
+    # and back
+    st, pr, outs = gpu_decompress(torch, blocks, lens, api.STREAM)
+    assert (st == 0).all()
+    for i, x in enumerate(xs):
+        assert outs[i] == x.tobytes()
+
+
+@pytest.mark.parametrize("p", [9, 11, 13, 15, 16])
+def test_ragged_fragment_batch_fuzz(torch, chk, p):
+    xs = [x[:32768] for x in _ragged_cases(200 + p, 64)]
+    host = np.concatenate(xs)
+    lens = [len(x) for x in xs]
+    blocks, _, _ = gpu_compress(torch, host, lens, p, api.FRAGMENT)
+    want = oracle_blocks(chk, host, lens, p, api.FRAGMENT)
+    for i, (a, b) in enumerate(zip(blocks, want)):
+        assert a == b, f"p={p} fragment {i} (n={lens[i]})"
+    st, pr, outs = gpu_decompress(torch, blocks, lens, api.FRAGMENT)
+    assert (st == 0).all() and pr.tolist() == lens
+    for i, x in enumerate(xs):
+        assert outs[i] == x.tobytes()
+
+
+def test_incompressible_and_all_zero_extremes(torch, chk):
+    rng = np.random.default_rng(9)
+    xs = [rng.integers(0, 256, 65536, dtype=np.uint8), np.zeros(65536, np.uint8),
+          rng.integers(0, 256, 32768, dtype=np.uint8), np.zeros(32768, np.uint8),
+          np.full(100000, 7, np.uint8)]
+    host = np.concatenate(xs)
+    lens = [len(x) for x in xs]
+    for p in (16, 15, 9):
+        blocks, _, _ = gpu_compress(torch, host, lens, p, api.STREAM)
+        assert blocks == oracle_blocks(chk, host, lens, p, api.STREAM)
+        st, _, outs = gpu_decompress(torch, blocks, lens, api.STREAM)
+        assert (st == 0).all() and [bytes(o) for o in outs] == [x.tobytes() for x in xs]
+
+
+# -------------------------------------------------------------------------------------------------
+# decompress
+# -------------------------------------------------------------------------------------------------
+def test_decode_reference_fixtures(torch, urls, golden_dir):
+    shipped = open(os.path.join(golden_dir, "urls.10K.snappy"), "rb").read()
+    un_s = gzip.open(os.path.join(golden_dir, "unaligned_uint64_test.snappy.gz")).read()
+    un_b = gzip.open(os.path.join(golden_dir, "unaligned_uint64_test.bin.gz")).read()
+    bad = open(os.path.join(golden_dir, "baddata3.snappy"), "rb").read()
+    st, pr, outs = gpu_decompress(torch, [shipped, un_s, bad], [len(urls), len(un_b), 130378], api.STREAM)
+    assert st.tolist() == [0, 0, -5]
+    assert outs[0] == urls and outs[1] == un_b
+    # the same three through the legacy single-call API
+    assert api.decompress(shipped, len(urls)) == (0, urls)
+    assert api.decompress(un_s, len(un_b)) == (0, un_b)
+    assert api.decompress(bad, 130378)[0] == GOLD["baddata3"]["decompress"]
+    n = api.get_uncompressed_length(bad)
+    assert list(n) == GOLD["baddata3"]["get_len"]
+    assert api.decompress_noheader(bad[n[0]:], 130378)[0] == GOLD["baddata3"]["noheader"]
+
+
+@pytest.mark.parametrize("e", GOLD["negative"], ids=lambda e: e["hex"] or "empty")
+def test_negative_vectors(torch, e):
+    raw = bytes.fromhex(e["hex"])
+    rc, val = api.get_uncompressed_length(raw)
+    assert rc == e["get_len"][0]
+    assert api.decompress(raw, e["dst_len"])[0] == e["decompress"]
+    st, _, _ = gpu_decompress(torch, [raw], [e["dst_len"]], api.STREAM)
+    assert st[0] == e["decompress"]
+    if "noheader" in e:
+        rc_nh, produced, body = api.decompress_noheader(raw[rc:], e["dst_len"])
+        assert rc_nh == e["noheader"][0]
+        if rc_nh == 0:
+            assert produced == e["noheader"][1] and body.hex() == e["noheader"][2]
+
+
+def test_corrupted_streams_match_oracle_status(torch, chk):
+    """Mutated streams, one batch: every status code (and output on success) must equal the
+    checker's.  Streams with a tag header cut off by the end of input are excluded (undefined in
+    the reference; both the oracle and the kernel return -5 there, checked separately below)."""
+    from test_oracle import _has_truncated_tag
+    rng = np.random.default_rng(77)
+    P = oracle.Port()
+    streams, caps = [], []
+    for x in _ragged_cases(300, 120):
+        x = x[:20000]
+        c = bytearray(P.compress(x, 15))
+        for _ in range(3):
+            m = bytearray(c)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            cut = int(rng.integers(0, 3))
+            if cut and len(m) > cut:
+                m = m[:-cut]
+            if _has_truncated_tag(bytes(m)):
+                continue
+            streams.append(bytes(m))
+            caps.append(int(rng.choice([len(x), len(x) + 7, max(len(x) - 3, 0), 2 * len(x) + 64])))
+    st, pr, outs = gpu_decompress(torch, streams, caps, api.STREAM)
+    for i, (s, cap) in enumerate(zip(streams, caps)):
+        want_rc, want_out = chk.decompress(s, cap)
+        assert st[i] == want_rc, (i, s.hex()[:60], cap)
+        if want_rc == 0:
+            n = P.get_uncompressed_length(s)
+            _, prod, body = chk.decompress_noheader(s[n[0]:], cap)
+            assert outs[i] == body and pr[i] == prod
+    # noheader form on the same bodies
+    bodies = [s[P.get_uncompressed_length(s)[0]:] if P.get_uncompressed_length(s)[0] > 0 else s for s in streams]
+    st2, pr2, outs2 = gpu_decompress(torch, bodies, caps, api.FRAGMENT)
+    for i, (s, cap) in enumerate(zip(bodies, caps)):
+        rc, prod, body = chk.decompress_noheader(s, cap)
+        assert st2[i] == rc, (i, s.hex()[:60], cap)
+        if rc == 0:
+            assert pr2[i] == prod and outs2[i] == body
+
+
+def test_truncated_tag_is_malformed(torch):
+    # copy-2 tag with one of two offset bytes, long literal with its length byte missing
+    st, _, _ = gpu_decompress(torch, [bytes.fromhex("0800610a01"), bytes.fromhex("0800 61f0".replace(" ", "")),
+                                      bytes.fromhex("08006103010000")], [64, 64, 64], api.STREAM)
+    assert st.tolist() == [-5, -5, -5]
+
+
+def test_foreign_stream_features(torch, chk):
+    """Things this encoder never emits but the decoder must accept: 4-byte-offset copies,
+    copies reaching back across 32 KiB, literals with 3- and 4-byte length fields."""
+    rng = np.random.default_rng(3)
+    first = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+
+    def lit(b):
+        n = len(b) - 1
+        if n < 60:
+            return bytes([n << 2]) + b
+        k = (n.bit_length() + 7) // 8
+        return bytes([(59 + k) << 2]) + n.to_bytes(k, "little") + b
+
+    def varint(v):
+        out = b""
+        while v >= 128:
+            out += bytes([v & 127 | 128])
+            v >>= 7
+        return out + bytes([v])
+    body = lit(first) + bytes([3 | (63 << 2)]) + (70000).to_bytes(4, "little") \
+        + bytes([2 | (63 << 2)]) + (40000).to_bytes(2, "little") + lit(b"xyz") \
+        + bytes([0xFC]) + (2).to_bytes(4, "little") + b"QRS"
+    want = first + first[:64] + (first + first[:64])[70064 - 40000:70064 - 40000 + 64] + b"xyz" + b"QRS"
+    stream = varint(len(want)) + body
+    rc, out = chk.decompress(stream, len(want))
+    assert rc == 0 and out == want
+    st, pr, outs = gpu_decompress(torch, [stream], [len(want)], api.STREAM)
+    assert st[0] == 0 and outs[0] == want
+
+
+# -------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config sizes are far beyond what the oracle can check in
+# seconds: check size-independent properties there)
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,seed,block,p,mode", [
+    (api.WG_TEXT, 0xC5A90001, 65536, 16, api.STREAM),
+    (api.WG_LOW, 0xC5A90005, 65536, 16, api.STREAM),
+    (api.WG_PAGE, 0xC5A90004, 4096, 13, api.FRAGMENT),
+])
+def test_large_batch_round_trip_and_sampled_parity(torch, chk, kind, seed, block, p, mode):
+    """256 MiB batch: encode -> decode round trip on the GPU for every block, compressed
+    lengths within the slot bound, and a sample of blocks bit-exact against the oracle."""
+    total = 256 << 20
+    nblocks = total // block
+    d_in = api.generate(kind, seed, 0, nblocks, block)
+    b = api.Batch([block] * nblocks)
+    d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
+    api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len,
+                       p, mode, b.d_ws)
+    d_back = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    cap = torch.full((nblocks,), block, dtype=torch.int32, device="cuda")
+    status = torch.full((nblocks,), -99, dtype=torch.int32, device="cuda")
+    produced = torch.zeros(nblocks, dtype=torch.int32, device="cuda")
+    api.decompress_batch(d_out, b.d_out_off, b.d_out_len, d_back, b.d_in_off, cap, status, produced, mode)
+    torch.cuda.synchronize()
+    assert (status == 0).all().item()
+    assert (produced == block).all().item()
+    assert torch.equal(d_back, d_in)
+    lens = b.d_out_len.cpu().numpy()
+    assert (lens > 0).all() and (lens <= api.max_compressed_length(block)).all()
+    rng = np.random.default_rng(1)
+    for i in rng.choice(nblocks, 48, replace=False):
+        i = int(i)
+        src = d_in[i * block:(i + 1) * block].cpu().numpy()
+        o = int(b.out_off[i])
+        got = bytes(d_out[o:o + int(lens[i])].cpu().numpy())
+        want = chk.compress(src, p) if mode == api.STREAM else chk.compress_fragment(src, p)
+        assert got == want, f"block {i}"
