@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Snappy block-codec hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch that is already resident in HBM:
+compress every block of the batch (snappy_compress_fragments + snappy_stitch_blocks), then
+decompress every block back (snappy_decompress_blocks).  The default workload is BASELINE.json
+configs[1]: 1 GiB of the G_text synthetic per GPU, cut into 65536-byte blocks, STREAM mode
+(csnappy_compress / csnappy_decompress semantics), table power 16.  Blocks are independent, so
+N GPUs take N disjoint block ranges (weak scaling: 1 GiB per rank), with no data-path collective.
+
+Rank 0 prints ONE JSON line.  `value` = uncompressed bytes round-tripped per second, whole job.
+`roofline` is for the dominant kernel, from HIP events recorded on the launch stream inside the
+timed region.  `cpu_baseline` is the reference C code (oracle/_ref, "reference") or its
+restatement (oracle/, "port") on this box's host cores over a bounded sample of the same input.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (generator kind, seed, block bytes, table power, mode, description)
+    "text": (0, 0xC5A90001, 65536, 16, 0, "G_text synthetic (URL-like tokens)"),
+    "low": (1, 0xC5A90005, 65536, 16, 0, "G_low synthetic (runs / short periods)"),
+    "page": (2, 0xC5A90004, 4096, 13, 1, "G_page synthetic (zram-style 4 KiB page mix)"),
+    "urls": (-1, 0, 65536, 16, 0, "testdata/urls.10K replicated end to end"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_measured_traffic(workload, p):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by tools/profile_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+        return t.get(f"{workload}_p{p}", {}).get("snappy_compress_fragments_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(kind, seed, block, p, mode, nblocks_avail, target_s, urls=None):
+    """Time the CPU path on a bounded sample of the same workload, all host cores."""
+    import oracle
+    from csnappy_amd import api
+    codec = oracle.best()
+    cores = os.cpu_count() or 1
+
+    def sample(nb):
+        if kind >= 0:
+            return api.generate_host(kind, seed, 0, nb, block)
+        rep = np.frombuffer(urls, dtype=np.uint8)
+        return np.resize(rep, nb * block)
+
+    def run(nb, threads):
+        host = sample(nb)
+        b = api.Batch([block] * nb, device=None)
+        t0 = time.perf_counter()
+        out, out_len = oracle.batch_compress(codec, host, b.in_off, b.in_len, b.out_off, b.out_bytes,
+                                             p, mode, threads=threads)
+        t1 = time.perf_counter()
+        cap = np.full(nb, block, dtype=np.uint32)
+        back, status, _ = oracle.batch_decompress(codec, out, b.out_off, out_len, b.in_off, cap,
+                                                  nb * block, mode, threads=threads)
+        t2 = time.perf_counter()
+        assert (status == 0).all() and np.array_equal(back, host)
+        return t1 - t0, t2 - t1
+
+    probe = max(cores * 4, (8 << 20) // block)
+    tc, td = run(probe, cores)
+    per_block = (tc + td) / probe
+    nb = int(min(nblocks_avail, max(probe, target_s / per_block)))
+    nb = min(nb, (6 << 30) // block)  # bound host memory
+    tc, td = run(nb, cores)
+    gib = nb * block / 2.0 ** 30
+    return {
+        "value": round(gib / (tc + td), 4), "unit": "GiB/s", "cores": cores, "kind": codec.kind,
+        "sample": f"first {nb} blocks x {block} B of the same workload ({gib:.3f} GiB), "
+                  f"compress {tc:.2f} s + decompress {td:.2f} s on {cores} threads "
+                  "(one block range per thread)",
+        "compress_gibs": round(gib / tc, 4), "decompress_gibs": round(gib / td, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="text")
+    ap.add_argument("--gib", type=float, default=1.0, help="uncompressed GiB per GPU")
+    ap.add_argument("--p", type=int, default=None, help="table power (default per workload)")
+    ap.add_argument("--block", type=int, default=None, help="block bytes (default per workload)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time an RCCL all_gather of the compacted per-rank streams (reported "
+                         "separately; never part of `value`)")
+    args = ap.parse_args()
+
+    import torch
+    from csnappy_amd import api
+    from csnappy_amd import shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    api.require_device()
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    kind, seed, block, p, mode, desc = WORKLOADS[args.workload]
+    block = args.block or block
+    p = args.p or p
+    nb = max(1, int(args.gib * 2 ** 30) // block)  # blocks per rank
+    first, _ = shard.block_range(nb * world, rank, world)
+
+    # ---- input resident in HBM -------------------------------------------------------------------
+    urls = None
+    if kind >= 0:
+        d_in = api.generate(kind, seed, first, nb, block)
+    else:
+        urls = open(os.path.join(ROOT, "tests", "golden", "urls.10K"), "rb").read()
+        rep = torch.from_numpy(np.frombuffer(urls, dtype=np.uint8).copy()).cuda()
+        idx = (torch.arange(nb * block, device="cuda", dtype=torch.int64) + first * block) % len(urls)
+        d_in = rep[idx]
+        del idx
+    b = api.Batch([block] * nb)
+    d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
+    d_back = torch.zeros(nb * block, dtype=torch.uint8, device="cuda")
+    cap = torch.full((nb,), block, dtype=torch.int32, device="cuda")
+    status = torch.full((nb,), -99, dtype=torch.int32, device="cuda")
+    produced = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len,
+                           p, mode, b.d_ws)
+        api.decompress_batch(d_out, b.d_out_off, b.d_out_len, d_back, b.d_in_off, cap, status, produced,
+                             mode)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if args.warmup == 0:
+        step()
+        torch.cuda.synchronize()
+    # results are checked outside the timed region: every block round-trips
+    assert (status == 0).all().item(), "decompress reported an error"
+    assert torch.equal(d_back, d_in), "round trip differs from the input"
+    comp_bytes = int(b.d_out_len.to(torch.int64).sum().item())
+
+    # ---- timed region: exactly K steps ----------------------------------------------------------
+    api.get_kernel_timing()
+    api.set_kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    api.set_kernel_timing(False)
+    kt = api.get_kernel_timing()
+
+    t_max = elapsed
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = t.item()
+    n_bytes = nb * block
+    kernels = {k: {"avg_ms": round(ms / max(c, 1), 4), "launches": c} for k, (ms, c) in kt.items()}
+
+    gather = None
+    if args.gather and dist is not None:
+        gather = shard.time_gather_compacted(d_out, b, dist, world)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (this GPU) ----------------------------------------------
+    # algorithmic bytes per launch: compress N_in + C_out, decompress C_in + N_out
+    alg = {"snappy_compress_fragments": n_bytes + comp_bytes,
+           "snappy_stitch_blocks": comp_bytes,  # <= half of C is moved (read + write)
+           "snappy_decompress_blocks": comp_bytes + n_bytes}
+    dom = max(("snappy_compress_fragments", "snappy_decompress_blocks"),
+              key=lambda k: kernels[k]["avg_ms"])
+    dom_s = kernels[dom]["avg_ms"] / 1e3
+    achieved = alg[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
+    traffic = load_measured_traffic(args.workload, p) if dom == "snappy_compress_fragments" else None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
+                "traffic": traffic}
+
+    gibs = lambda ms: round(n_bytes * world / (ms / 1e3) / 2 ** 30, 3) if ms > 0 else None
+    out = {
+        "metric": "GiB/s compress+decompress on 64KiB blocks" if block == 65536 else
+                  f"GiB/s compress+decompress on {block}-byte blocks",
+        "value": round(n_bytes * world * args.steps / t_max / 2 ** 30, 4),
+        "unit": "GiB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_max / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic" if kind >= 0 else "urls.10K replicated",
+        "config": {"workload": f"{args.gib:g} GiB per GPU of {desc}, {block}-byte blocks, "
+                               f"{'STREAM' if mode == 0 else 'FRAGMENT'} mode, table power {p}, "
+                               "compress then decompress (round trip), inputs resident in HBM",
+                   "block_bytes": block, "blocks_per_gpu": nb, "table_power": p,
+                   "mode": "STREAM" if mode == 0 else "FRAGMENT", "seed": hex(seed),
+                   "sharding": f"block ranges, {world} rank(s), no data-path collective"},
+        "compressed_ratio": round(comp_bytes / n_bytes, 6),
+        "compress_gibs": gibs(kernels["snappy_compress_fragments"]["avg_ms"]
+                              + kernels["snappy_stitch_blocks"]["avg_ms"]),
+        "decompress_gibs": gibs(kernels["snappy_decompress_blocks"]["avg_ms"]),
+        "kernels": kernels,
+        "roofline": roofline,
+    }
+    if gather is not None:
+        out["gather"] = gather
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(kind, seed, block, p, mode, nb, args.cpu_seconds, urls)
+        except Exception as e:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": f"failed: {e!r}"}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ LEGACY_SYMBOLS = [
 HIP_SYMBOLS = [
     "csnappy_hip_device_count", "csnappy_hip_last_error", "csnappy_hip_compress_workspace_size",
     "csnappy_hip_compress_batch", "csnappy_hip_decompress_batch", "csnappy_hip_set_kernel_timing",
-    "csnappy_hip_get_kernel_timing", "csnappy_hip_workload_generate",
+    "csnappy_hip_get_kernel_timing", "csnappy_hip_workload_generate", "csnappy_hip_compact_batch",
     "csnappy_workload_generate_host",
 ]
 
@@ -74,10 +74,12 @@ def lib():
                                              C.c_size_t, vp]
     L.csnappy_hip_decompress_batch.restype = i32
     L.csnappy_hip_decompress_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, i32, vp]
+    L.csnappy_hip_compact_batch.restype = i32
+    L.csnappy_hip_compact_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.csnappy_hip_set_kernel_timing.restype = None
     L.csnappy_hip_set_kernel_timing.argtypes = [i32]
     L.csnappy_hip_get_kernel_timing.restype = None
-    L.csnappy_hip_get_kernel_timing.argtypes = [C.POINTER(C.c_float)]
+    L.csnappy_hip_get_kernel_timing.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.csnappy_hip_workload_generate.restype = i32
     L.csnappy_hip_workload_generate.argtypes = [i32, u64, u64, u32, u32, vp, vp]
     L.csnappy_workload_generate_host.restype = None
@@ -191,14 +193,23 @@ def decompress_batch(d_in, in_off, in_len, d_out, out_off, out_cap, status, prod
     _check(rc, "csnappy_hip_decompress_batch")
 
 
+def compact_batch(d_out, out_off, out_len, dense_off, dense):
+    rc = lib().csnappy_hip_compact_batch(d_out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(),
+                                         dense_off.data_ptr(), out_len.numel(), dense.data_ptr(),
+                                         _stream())
+    _check(rc, "csnappy_hip_compact_batch")
+
+
 def set_kernel_timing(on):
     lib().csnappy_hip_set_kernel_timing(1 if on else 0)
 
 
 def get_kernel_timing():
-    ms = (C.c_float * 4)()
-    lib().csnappy_hip_get_kernel_timing(ms)
-    return {"compress_fragments": ms[0], "stitch_blocks": ms[1], "decompress_blocks": ms[2]}
+    """-> {kernel: (total_ms, launches)} since the previous read (waits for the events)."""
+    ms, cnt = (C.c_float * 4)(), (C.c_uint32 * 4)()
+    lib().csnappy_hip_get_kernel_timing(ms, cnt)
+    names = ("snappy_compress_fragments", "snappy_stitch_blocks", "snappy_decompress_blocks")
+    return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
 
 def generate(kind, seed, first_block, nblocks, block_len, device="cuda"):

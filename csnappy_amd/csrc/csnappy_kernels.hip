@@ -82,11 +82,6 @@ DEVINL uint32_t rdlane(uint32_t v, uint32_t l)
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
 
-DEVINL uint32_t uni(uint32_t v)
-{
-	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
 DEVINL uint32_t first_lane(uint64_t m)
 {
 	return (uint32_t)__builtin_ctzll(m);
@@ -631,6 +626,34 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 }
 
 /* ==========================================================================================
+ * COMPACT: pack the slot-strided outputs into one dense stream (what the reference's callers do
+ * with memcpy after each call; needed before the multi-GPU gather)
+ * ======================================================================================== */
+extern "C" __global__ void __launch_bounds__(256)
+snappy_compact_stream(const uint8_t *out, const uint64_t *out_off, const uint32_t *out_len,
+		      const uint64_t *dense_off, uint8_t *dense)
+{
+	const uint32_t blk = blockIdx.x, tid = threadIdx.x;
+	const uint8_t *s = out + out_off[blk];
+	uint8_t *d = dense + dense_off[blk];
+	const uint32_t n = out_len[blk];
+	/* destination-aligned dwords assembled from (possibly misaligned) source bytes */
+	const uint32_t head = min(n, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
+	if (tid < head)
+		d[tid] = s[tid];
+	const uint32_t words = (n - head) >> 2;
+	const uint8_t *sb = s + head;
+	const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(sb) & 3);
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sb - sh);
+	uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
+	for (uint32_t k = tid; k < words; k += 256)
+		d32[k] = sh ? __builtin_amdgcn_alignbyte(s32[k + 1], s32[k], sh) : s32[k];
+	const uint32_t tail = head + 4 * words;
+	if (tail + tid < n)
+		d[tail + tid] = s[tail + tid];
+}
+
+/* ==========================================================================================
  * workload generator kernel (bench/test input; see workload_gen.h)
  * ======================================================================================== */
 extern "C" __global__ void __launch_bounds__(64)
@@ -646,8 +669,6 @@ workload_generate(int kind, uint64_t seed, uint64_t first_block, uint32_t nblock
  * host side of the C-ABI
  * ---------------------------------------------------------------------------------------- */
 thread_local char g_last_error[256] = "";
-bool g_timing = false;
-float g_ms[4] = { 0, 0, 0, 0 };
 
 bool hip_ok(hipError_t e, const char *what)
 {
@@ -657,38 +678,36 @@ bool hip_ok(hipError_t e, const char *what)
 	return false;
 }
 
+/* Per-kernel timing for bench.py: event pairs are recorded on the launch stream around each
+ * kernel (no host synchronisation in the launch path) and resolved when the totals are read. */
+struct Pending {
+	int slot;
+	hipEvent_t a, b;
+};
+bool g_timing = false;
+Pending g_pending[4096];
+int g_npending = 0;
+
 struct Timer {
-	hipEvent_t a = nullptr, b = nullptr;
 	hipStream_t st;
+	hipEvent_t a = nullptr, b = nullptr;
 	bool on;
-	explicit Timer(hipStream_t s) : st(s), on(g_timing)
-	{
-		if (on) {
-			hipEventCreate(&a);
-			hipEventCreate(&b);
-		}
-	}
+	explicit Timer(hipStream_t s) : st(s), on(g_timing && g_npending < 4096) {}
 	void start()
 	{
-		if (on)
-			hipEventRecord(a, st);
+		if (!on)
+			return;
+		(void)hipEventCreate(&a);
+		(void)hipEventCreate(&b);
+		(void)hipEventRecord(a, st);
 	}
 	void stop(int slot)
 	{
 		if (!on)
 			return;
-		hipEventRecord(b, st);
-		hipEventSynchronize(b);
-		float ms = 0;
-		hipEventElapsedTime(&ms, a, b);
-		g_ms[slot] = ms;
-	}
-	~Timer()
-	{
-		if (on) {
-			hipEventDestroy(a);
-			hipEventDestroy(b);
-		}
+		(void)hipEventRecord(b, st);
+		g_pending[g_npending++] = Pending{ slot, a, b };
+		on = g_timing && g_npending < 4096;
 	}
 };
 
@@ -719,10 +738,22 @@ void csnappy_hip_set_kernel_timing(int enable)
 	g_timing = enable != 0;
 }
 
-void csnappy_hip_get_kernel_timing(float ms[4])
+void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4])
 {
-	for (int i = 0; i < 4; ++i)
-		ms[i] = g_ms[i];
+	for (int i = 0; i < 4; ++i) {
+		ms[i] = 0;
+		launches[i] = 0;
+	}
+	for (int i = 0; i < g_npending; ++i) {
+		float t = 0;
+		(void)hipEventSynchronize(g_pending[i].b);
+		(void)hipEventElapsedTime(&t, g_pending[i].a, g_pending[i].b);
+		ms[g_pending[i].slot] += t;
+		launches[g_pending[i].slot]++;
+		(void)hipEventDestroy(g_pending[i].a);
+		(void)hipEventDestroy(g_pending[i].b);
+	}
+	g_npending = 0;
 }
 
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len)
@@ -779,7 +810,6 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	t.stop(0);
 	if (!hip_ok(hipGetLastError(), "launch snappy_compress_fragments"))
 		return CSNAPPY_HIP_E_RUNTIME;
-	g_ms[1] = 0;
 	if (fpb > 1) {
 		t.start();
 		hipLaunchKernelGGL(snappy_stitch_blocks, dim3(nblocks * fpb), dim3(256), 0, st, A);
@@ -816,6 +846,19 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 	hipLaunchKernelGGL(snappy_decompress_blocks, dim3(nblocks), dim3(64), 0, st, A);
 	t.stop(2);
 	if (!hip_ok(hipGetLastError(), "launch snappy_decompress_blocks"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	return 0;
+}
+
+int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_len,
+			      const uint64_t *d_dense_off, uint32_t nblocks, void *d_dense, void *stream)
+{
+	if (nblocks == 0)
+		return 0;
+	hipLaunchKernelGGL(snappy_compact_stream, dim3(nblocks), dim3(256), 0,
+			   static_cast<hipStream_t>(stream), static_cast<const uint8_t *>(d_out), d_out_off,
+			   d_out_len, d_dense_off, static_cast<uint8_t *>(d_dense));
+	if (!hip_ok(hipGetLastError(), "launch snappy_compact_stream"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	return 0;
 }

@@ -77,13 +77,23 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 				 int32_t *d_status, uint32_t *d_produced, int mode, void *stream);
 
 /*
- * Per-kernel timing for bench.py: when enabled, the batch calls bracket each kernel with
- * hipEvents on `stream`, synchronise the stream before returning, and remember the durations.
- * slots: [0] compress_fragments  [1] stitch_blocks  [2] decompress_blocks  (milliseconds of the
- * most recent call; 0 when that kernel did not run).
+ * Pack the slot-strided output of csnappy_hip_compress_batch into one dense stream:
+ * block b's d_out_len[b] bytes go to d_dense + d_dense_off[b] (the caller supplies the exclusive
+ * scan of the lengths).  This is what the reference's callers do with their own memcpy after
+ * each csnappy_compress call (block_compressor.c:316-334); it precedes the multi-GPU gather.
+ */
+int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_len,
+			      const uint64_t *d_dense_off, uint32_t nblocks, void *d_dense, void *stream);
+
+/*
+ * Per-kernel timing for bench.py: while enabled, the batch calls record a hipEvent pair on
+ * `stream` around each kernel (nothing synchronises in the launch path).
+ * csnappy_hip_get_kernel_timing() waits for the recorded events, returns the summed duration
+ * (milliseconds) and the number of launches per kernel since the previous read, and resets.
+ * slots: [0] snappy_compress_fragments  [1] snappy_stitch_blocks  [2] snappy_decompress_blocks
  */
 void csnappy_hip_set_kernel_timing(int enable);
-void csnappy_hip_get_kernel_timing(float ms[4]);
+void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4]);
 
 /*
  * Synthetic workloads of SURVEY.md section 8(d) (not part of the reference; bench/test input).

@@ -363,3 +363,14 @@ def test_large_batch_round_trip_and_sampled_parity(torch, chk, kind, seed, block
         got = bytes(d_out[o:o + int(lens[i])].cpu().numpy())
         want = chk.compress(src, p) if mode == api.STREAM else chk.compress_fragment(src, p)
         assert got == want, f"block {i}"
+
+
+def test_compact_stream_equals_concatenation(torch, urls):
+    from csnappy_amd import shard
+    data = np.frombuffer(urls, dtype=np.uint8)
+    lens = api.Batch.uniform(len(urls), 4096, device=None).in_len
+    blocks, b, d_out = gpu_compress(torch, data, lens, 13, api.FRAGMENT)
+    dense, off = shard.compact(d_out, b.d_out_off, b.d_out_len)
+    torch.cuda.synchronize()
+    assert bytes(dense.cpu().numpy()) == b"".join(blocks)
+    assert sha(b"".join(blocks)) == GOLD["urls_blocks"]["4k_p13"]["sha256"]

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Digest rocprofv3 outputs (tools/profile_gpu.sh) into one small JSON for profiles/.
+
+Kernel durations come from the --kernel-trace --stats pass.  HBM traffic comes from the two PMC
+passes and is corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a wide
+(16 B/lane) coalesced read -- which is how the compress kernel stages its window -- so it is
+doubled; WRITE_SIZE is taken as is (uncalibrated, per the guide)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, args = sys.argv[1], sys.argv[2]
+
+
+def rows(pattern):
+    for path in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(path, newline="") as f:
+            yield from csv.DictReader(f)
+
+
+summary = {"bench_args": args, "kernels": {}, "pmc": {}}
+for r in rows("stats/**/*kernel_stats.csv"):
+    name = r.get("Name", "")
+    if "snappy" in name or "workload" in name:
+        summary["kernels"][name.split("(")[0]] = {
+            "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
+            "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "percent": float(r["Percentage"])}
+
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in rows(f"{counter[:5].lower()}/**/*counter_collection.csv"):
+        if r.get("Counter_Name") != counter:
+            continue
+        k = r.get("Kernel_Name", "").split("(")[0]
+        if "snappy" not in k:
+            continue
+        acc[k][0] += float(r["Counter_Value"])
+        acc[k][1] += 1
+    for k, (tot, n) in acc.items():
+        summary["pmc"].setdefault(k, {})[counter + "_KiB_per_launch"] = tot / max(n, 1)
+        summary["pmc"][k]["launches_" + counter] = n
+
+for k, v in summary["pmc"].items():
+    if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+        v["hbm_bytes_per_launch_corrected"] = int((2 * v["FETCH_SIZE_KiB_per_launch"]
+                                                   + v["WRITE_SIZE_KiB_per_launch"]) * 1024)
+try:
+    summary["bench_line"] = json.loads(open(os.path.join(out, "bench_stats.json")).read().strip().splitlines()[-1])
+except Exception as e:  # noqa
+    summary["bench_line"] = f"unreadable: {e!r}"
+print(json.dumps(summary, indent=1))
