@@ -43,7 +43,6 @@ constexpr uint32_t kFragment = 32768;    /* kBlockSize, csnappy_compress.c:85-86
 constexpr uint32_t kMargin = 15;         /* kInputMarginBytes, csnappy_compress.c:468 */
 constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
 constexpr uint32_t kScratchSlot = 38400; /* >= max_compressed_length(32768)=38261, 256-aligned */
-constexpr uint32_t kShortLiteral = 24;   /* literals up to this are copied lane-per-record */
 
 #define DEVINL __device__ __forceinline__
 
@@ -62,6 +61,7 @@ struct CompressArgs {
 	uint32_t s_entries; /* conflict-scratch entries (power of two) */
 	int p;
 	int mode;
+	unsigned long long *prof; /* debug cycle counters (PROF instantiation only) */
 };
 
 struct DecompressArgs {
@@ -172,12 +172,65 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 }
 
 /* ==========================================================================================
- * COMPRESS: one wave per fragment
+ * COMPRESS: one workgroup (2 waves) per fragment: wave 0 parses, wave 1 emits
+ *
+ * The parser's dependent chain (LDS round trips + single-wave instruction issue) is what bounds
+ * the kernel, so everything that is not on that chain runs on another SIMD: the parser only
+ * queues (literal, copy) records into an LDS ring; the emitter wave encodes them
+ * (EmitLiteral/EmitCopy), stages the bytes in LDS and flushes them to HBM with aligned 16 B/lane
+ * stores.  The two waves meet at one s_barrier per 64 records (double-buffered ring).
+ *
+ * Step logic (restated lane by lane in tests/wave_model.py::compress_fragment_v2 and fuzzed
+ * against the oracle on the CPU):
+ *   dense step   the 64 lanes take 64 CONSECUTIVE positions starting at the cursor.  Every lane
+ *                hashes its 4 bytes, gathers table[h], and computes a lane-local match length
+ *                (up to kLocalMatch bytes) against its candidate.  The step is truncated at the
+ *                first lane that shares a hash slot with an earlier lane (exactness, see
+ *                DESIGN.md 4.1).  The chain of matches through the step -- match at lane i of
+ *                length L, insert lane i+L-1, re-match probe at lane i+L, 32 stride-1 scan probes
+ *                after it (csnappy_compress.c:535-598) -- is then walked on the scalar unit, so
+ *                one step usually retires several copies.
+ *   sparse step  once a scan has made 32 probes without a match the reference strides by 2, 3..
+ *                (:542); lanes then take the next 64 probe positions of that stride rule and a
+ *                step ends at its first match.
  * ======================================================================================== */
-extern "C" __global__ void __launch_bounds__(64) snappy_compress_fragments(CompressArgs A)
+constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
+constexpr uint32_t kBigRecord = 64;   /* records encoding to more than this bypass the staging */
+constexpr uint32_t kFlushAt = 512;   /* staged bytes that trigger a coalesced flush */
+constexpr uint32_t kStageBytes = 16 + kFlushAt + 64 * kBigRecord + 16; /* LDS output staging */
+constexpr uint32_t kRingBytes = 2 * 64 * 16 + 16; /* two batches of 64 records (4 dwords each) + two count words */
+
+DEVINL uint64_t lane_range(int a, int e) /* bits a..e inclusive, 0 <= a <= e <= 63 */
+{
+	return ((~0ull) >> (63 - e)) & ((~0ull) << a);
+}
+
+/* 16 bytes at an arbitrary byte index of LDS as four little-endian dwords */
+DEVINL void lds_rd128(const uint32_t *w, uint32_t byte, uint32_t out[4])
+{
+	const uint32_t d = byte >> 2, sh = byte & 3;
+	const uint32_t a = w[d], b = w[d + 1], c = w[d + 2], e = w[d + 3], f = w[d + 4];
+	out[0] = __builtin_amdgcn_alignbyte(b, a, sh);
+	out[1] = __builtin_amdgcn_alignbyte(c, b, sh);
+	out[2] = __builtin_amdgcn_alignbyte(e, c, sh);
+	out[3] = __builtin_amdgcn_alignbyte(f, e, sh);
+}
+
+/* Orders this wave's LDS accesses for the compiler.  The LDS pipeline executes one wave's
+ * instructions in issue order, so cross-lane exchange inside a wave needs no hardware wait. */
+DEVINL void wave_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+template <bool PROF>
+__device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const uint32_t lane = threadIdx.x;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t role = tid >> 6; /* 0 = parser, 1 = emitter (wave-uniform) */
 	const uint32_t id = blockIdx.x;
 	const uint32_t blk = id / A.fpb, fi = id - blk * A.fpb;
 	const uint32_t len = A.in_len[blk];
@@ -189,27 +242,14 @@ extern "C" __global__ void __launch_bounds__(64) snappy_compress_fragments(Compr
 	const uint32_t shift = 33 - ws;
 	const uint8_t *src = A.in + A.in_off[blk] + foff;
 
-	uint8_t *dst;
-	uint32_t hdr = 0;
-	if (fi == 0) {
-		dst = A.out + A.out_off[blk];
-		if (A.mode == CSNAPPY_HIP_STREAM) {
-			/* encode_varint32, csnappy_compress.c:46-73 */
-			hdr = varint_len(len);
-			if (lane < hdr)
-				dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < hdr ? 0x80u : 0u));
-			dst += hdr;
-		}
-	} else {
-		dst = A.scratch + (uint64_t)(blk * (uint64_t)(A.fpb - 1) + (fi - 1)) * kScratchSlot;
-	}
-
-	/* ---- LDS carve: window | hash table | conflict scratch | record queue ---- */
+	/* ---- LDS carve: window | hash table | conflict scratch | record ring | output staging ---- */
 	uint32_t *win32 = reinterpret_cast<uint32_t *>(smem);
-	const uint8_t *win8 = smem;
+	uint8_t *win8 = smem;
 	uint16_t *tab = reinterpret_cast<uint16_t *>(smem + A.win_bytes);
 	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.win_bytes + (1u << A.p));
-	uint32_t *evq = S + A.s_entries; /* 2 dwords per record, 64 records */
+	uint32_t *ring = S + A.s_entries;       /* [2][64] records {lit_start, base, cand, copy_len} */
+	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
+	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
 	const uint32_t smask = A.s_entries - 1;
 
 	/* window: aligned 16 B chunks; byte i of the fragment sits at win8[wbase + i] */
@@ -218,222 +258,469 @@ extern "C" __global__ void __launch_bounds__(64) snappy_compress_fragments(Compr
 		const uint4 *g = reinterpret_cast<const uint4 *>(src - wbase);
 		uint4 *l = reinterpret_cast<uint4 *>(smem);
 		const uint32_t chunks = (wbase + n + 15) >> 4;
-		for (uint32_t k = lane; k < chunks; k += 64)
+		for (uint32_t k = tid; k < chunks; k += 128)
 			l[k] = g[k];
 	}
 	if (n >= kMargin) {
 		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
 		uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-		for (uint32_t k = lane; k < ((1u << ws) >> 4); k += 64)
+		for (uint32_t k = tid; k < ((1u << ws) >> 4); k += 128)
 			t4[k] = make_uint4(0, 0, 0, 0);
 		uint4 *s4 = reinterpret_cast<uint4 *>(S);
-		for (uint32_t k = lane; k < (A.s_entries >> 2); k += 64)
+		for (uint32_t k = tid; k < (A.s_entries >> 2); k += 128)
 			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 	}
 	__syncthreads();
 
-	uint32_t op = 0;        /* bytes of output already written */
-	uint32_t nev = 0;       /* records queued */
+	if (role == 1) {
+		/* =============================== EMITTER =============================== */
+		uint8_t *dst;
+		uint32_t hdr = 0;
+		if (fi == 0) {
+			dst = A.out + A.out_off[blk];
+			if (A.mode == CSNAPPY_HIP_STREAM) {
+				/* encode_varint32, csnappy_compress.c:46-73 */
+				hdr = varint_len(len);
+				if (lane < hdr)
+					dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < hdr ? 0x80u : 0u));
+				dst += hdr;
+			}
+		} else {
+			dst = A.scratch + (uint64_t)(blk * (uint64_t)(A.fpb - 1) + (fi - 1)) * kScratchSlot;
+		}
+		/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
+		 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
+		uint32_t gpos = 0, fill = 0;
+		uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+
+		auto drain = [&](bool final) {
+			wave_lds_fence();
+			uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
+			const uint32_t end = sa + fill;
+			uint32_t first_full = 0;
+			if (sa > 0) {
+				const uint32_t hend = min(16u, end);
+				if (lane >= sa && lane < hend)
+					gbase[lane] = stage[lane];
+				first_full = 1;
+			}
+			const uint32_t nfull = end >> 4;
+			for (uint32_t c = first_full + lane; c < nfull; c += 64)
+				reinterpret_cast<uint4 *>(gbase)[c] = reinterpret_cast<const uint4 *>(stage)[c];
+			const uint32_t tail0 = nfull << 4;
+			const uint32_t tail = (end > tail0 && (nfull >= 1 || sa == 0)) ? end - tail0 : 0;
+			if (final) {
+				if (lane < tail)
+					gbase[tail0 + lane] = stage[tail0 + lane];
+				gpos += fill;
+				fill = 0;
+				sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
+			} else if (nfull >= 1) {
+				uint8_t keep = 0;
+				if (lane < tail)
+					keep = stage[tail0 + lane];
+				wave_lds_fence();
+				if (lane < tail)
+					stage[lane] = keep;
+				gpos += tail0 - sa;
+				fill = tail;
+				sa = 0;
+			}
+			wave_lds_fence();
+		};
+
+		for (uint32_t b = 0;; b ^= 1) {
+			__syncthreads(); /* batch b is published */
+			const uint32_t cw = ring_cnt[b];
+			const uint32_t nev = cw & 0xffff;
+			const bool last_batch = (cw >> 16) != 0;
+			/* ---- encode up to 64 records (EmitLiteral + EmitCopy, csnappy_compress.c:332-415) ---- */
+			uint32_t lit_start = 0, lit_len = 0, coff = 0, clen = 0;
+			if (lane < nev) {
+				const uint4 r = reinterpret_cast<const uint4 *>(ring)[b * 64 + lane];
+				lit_start = r.x;
+				lit_len = r.y - r.x; /* literal [lit_start, base) */
+				coff = r.y - r.z;    /* base - candidate */
+				clen = r.w;
+			}
+			const uint32_t lhdr = lit_len == 0 ? 0 : lit_len <= 60 ? 1 : lit_len <= 256 ? 2 : 3;
+			const CopyPlan cp = plan_copy(clen, coff);
+			const uint32_t mine = lhdr + lit_len + cp.bytes;
+			uint64_t bigmask = __ballot(mine > kBigRecord);
+			uint32_t total;
+			const uint32_t excl = wave_excl_scan(mine, lane, &total);
+			uint32_t seg_lo = 0; /* first record of the current run of small records */
+			while (nev) {
+				const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
+				if (seg_hi > seg_lo) {
+					/* stage small records [seg_lo, seg_hi) */
+					const uint32_t run_base = rdlane(excl, seg_lo);
+					const uint32_t run_bytes = (seg_hi < 64 ? rdlane(excl, seg_hi & 63) : total) - run_base;
+					const bool in_run = lane >= seg_lo && lane < seg_hi;
+					uint8_t *o = stage + sa + fill + (excl - run_base);
+					if (in_run) {
+						if (lhdr == 1) {
+							o[0] = (uint8_t)((lit_len - 1) << 2);
+						} else if (lhdr == 2) {
+							o[0] = (uint8_t)(60 << 2);
+							o[1] = (uint8_t)(lit_len - 1);
+						}
+					}
+					for (uint32_t j = 0; __ballot(in_run && j < lit_len); ++j)
+						if (in_run && j < lit_len)
+							o[lhdr + j] = win8[wbase + lit_start + j];
+					if (in_run && clen) {
+						uint8_t *q = o + lhdr + lit_len;
+						const uint8_t lo = (uint8_t)(coff & 0xff), hi = (uint8_t)(coff >> 8);
+						for (uint32_t k = 0; k < cp.k64; ++k) {
+							q[0] = 0xfe; /* COPY_2 | (63 << 2) */
+							q[1] = lo;
+							q[2] = hi;
+							q += 3;
+						}
+						if (cp.k60) {
+							q[0] = 0xee; /* COPY_2 | (59 << 2) */
+							q[1] = lo;
+							q[2] = hi;
+							q += 3;
+						}
+						if (cp.last < 12 && coff < 2048) {
+							q[0] = (uint8_t)(1 + ((cp.last - 4) << 2) + ((coff >> 8) << 5));
+							q[1] = lo;
+						} else {
+							q[0] = (uint8_t)(2 + ((cp.last - 1) << 2));
+							q[1] = lo;
+							q[2] = hi;
+						}
+					}
+					fill += run_bytes;
+				}
+				if (!bigmask)
+					break;
+				/* ---- a big record: drain the staging, write it straight to HBM ---- */
+				const uint32_t e = first_lane(bigmask);
+				bigmask &= bigmask - 1;
+				drain(true);
+				const uint32_t ls = rdlane(lit_start, e), ll = rdlane(lit_len, e);
+				const uint32_t lh = rdlane(lhdr, e), co = rdlane(coff, e), cl = rdlane(clen, e);
+				const uint32_t k64 = rdlane(cp.k64, e), k60 = rdlane(cp.k60, e), last = rdlane(cp.last, e);
+				const uint32_t cbytes = rdlane(cp.bytes, e);
+				uint8_t *o = dst + gpos;
+				if (lane == 0) {
+					const uint32_t v = ll - 1;
+					if (lh == 1) {
+						o[0] = (uint8_t)(v << 2);
+					} else if (lh == 2) {
+						o[0] = (uint8_t)(60 << 2);
+						o[1] = (uint8_t)v;
+					} else if (lh == 3) {
+						o[0] = (uint8_t)(61 << 2);
+						o[1] = (uint8_t)(v & 0xff);
+						o[2] = (uint8_t)(v >> 8);
+					}
+				}
+				{
+					/* literal payload: destination-aligned dwords from the LDS window */
+					uint8_t *d = o + lh;
+					const uint32_t head = min(ll, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
+					if (lane < head)
+						d[lane] = win8[wbase + ls + lane];
+					const uint32_t words = (ll - head) >> 2;
+					uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
+					for (uint32_t k = lane; k < words; k += 64)
+						d32[k] = lds_rd32(win32, wbase + ls + head + 4 * k);
+					const uint32_t t0 = head + 4 * words;
+					if (t0 + lane < ll)
+						d[t0 + lane] = win8[wbase + ls + t0 + lane];
+				}
+				if (cl) {
+					uint8_t *q = o + lh + ll;
+					const uint32_t body = 3 * (k64 + k60);
+					for (uint32_t t = lane; t < cbytes; t += 64) {
+						uint8_t bb;
+						if (t < body) {
+							const uint32_t r = t % 3;
+							bb = r == 0 ? (t < 3 * k64 ? 0xfe : 0xee) : r == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
+						} else {
+							const uint32_t r = t - body;
+							const bool two = last < 12 && co < 2048;
+							bb = r == 0 ? (two ? (uint8_t)(1 + ((last - 4) << 2) + ((co >> 8) << 5))
+									   : (uint8_t)(2 + ((last - 1) << 2)))
+							     : r == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
+						}
+						q[t] = bb;
+					}
+				}
+				gpos += lh + ll + cbytes;
+				sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
+				seg_lo = e + 1;
+			}
+			if (last_batch)
+				break;
+			if (fill >= kFlushAt)
+				drain(false);
+		}
+		drain(true);
+		if (lane == 0) {
+			A.frag_len[id] = gpos;
+			if (A.fpb == 1)
+				A.out_len[blk] = hdr + gpos;
+		}
+		return;
+	}
+
+	/* ================================== PARSER ================================== */
+	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t_pub = 0, t0 = 0, t1 = 0;
+	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
+	if (PROF)
+		t_begin = __builtin_amdgcn_s_memtime();
+	/* records of the current batch live in four VGPRs, record r in lane r */
+	uint32_t r_lit = 0, r_base = 0, r_cand = 0, r_len = 0;
+	uint32_t nev = 0, batch = 0;
 	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
 
-	/* Encode and store the queued records (EmitLiteral + EmitCopy). */
-	auto flush = [&]() {
-		uint32_t lit_start = 0, lit_len = 0, coff = 0, clen = 0;
-		if (lane < nev) {
-			const uint32_t r0 = evq[2 * lane], r1 = evq[2 * lane + 1];
-			lit_start = r0 & 0xffff;
-			lit_len = r0 >> 16;
-			coff = r1 & 0xffff;
-			clen = r1 >> 16;
-		}
-		const uint32_t lhdr = lit_len == 0 ? 0 : lit_len <= 60 ? 1 : lit_len <= 256 ? 2 : 3;
-		const CopyPlan cp = plan_copy(clen, coff);
-		uint32_t total;
-		const uint32_t mine = lhdr + lit_len + cp.bytes;
-		const uint32_t excl = wave_excl_scan(mine, lane, &total);
-		uint8_t *o = dst + op + excl;
-		/* literal header, csnappy_compress.c:335-368 */
-		if (lhdr == 1) {
-			o[0] = (uint8_t)((lit_len - 1) << 2);
-		} else if (lhdr == 2) {
-			o[0] = (uint8_t)(60 << 2);
-			o[1] = (uint8_t)(lit_len - 1);
-		} else if (lhdr == 3) {
-			o[0] = (uint8_t)(61 << 2);
-			o[1] = (uint8_t)((lit_len - 1) & 0xff);
-			o[2] = (uint8_t)((lit_len - 1) >> 8);
-		}
-		/* short literal payloads: one lane per record */
-		const bool is_short = lit_len <= kShortLiteral;
-		for (uint32_t j = 0; __ballot(is_short && j < lit_len); ++j)
-			if (is_short && j < lit_len)
-				o[lhdr + j] = win8[wbase + lit_start + j];
-		/* long literal payloads: the whole wave per record */
-		for (uint64_t lm = __ballot(!is_short); lm; lm &= lm - 1) {
-			const uint32_t e = first_lane(lm);
-			const uint32_t ls = rdlane(lit_start, e), ll = rdlane(lit_len, e);
-			uint8_t *ob = dst + op + rdlane(excl, e) + rdlane(lhdr, e);
-			for (uint32_t j = lane; j < ll; j += 64)
-				ob[j] = win8[wbase + ls + j];
-		}
-		/* copy tags, csnappy_compress.c:373-415 */
-		if (clen) {
-			uint8_t *q = o + lhdr + lit_len;
-			const uint8_t lo = (uint8_t)(coff & 0xff), hi = (uint8_t)(coff >> 8);
-			for (uint32_t k = 0; k < cp.k64; ++k) {
-				q[0] = 0xfe; /* COPY_2 | (63 << 2) */
-				q[1] = lo;
-				q[2] = hi;
-				q += 3;
-			}
-			if (cp.k60) {
-				q[0] = 0xee; /* COPY_2 | (59 << 2) */
-				q[1] = lo;
-				q[2] = hi;
-				q += 3;
-			}
-			if (cp.last < 12 && coff < 2048) {
-				q[0] = (uint8_t)(1 + ((cp.last - 4) << 2) + ((coff >> 8) << 5));
-				q[1] = lo;
-			} else {
-				q[0] = (uint8_t)(2 + ((cp.last - 1) << 2));
-				q[1] = lo;
-				q[2] = hi;
-			}
-		}
-		op += total;
+	auto publish = [&](bool last) {
+		unsigned long long tp = 0;
+		if (PROF)
+			tp = __builtin_amdgcn_s_memtime();
+		reinterpret_cast<uint4 *>(ring)[batch * 64 + lane] = make_uint4(r_lit, r_base, r_cand, r_len);
+		if (lane == 0)
+			ring_cnt[batch] = nev | (last ? 0x10000u : 0u);
+		__syncthreads();
+		batch ^= 1;
 		nev = 0;
+		if (PROF)
+			t_pub += __builtin_amdgcn_s_memtime() - tp;
+	};
+	auto add_record = [&](uint32_t lit_start, uint32_t base, uint32_t cnd, uint32_t clen) {
+		const bool slot = lane == nev;
+		r_lit = slot ? lit_start : r_lit;
+		r_base = slot ? base : r_base;
+		r_cand = slot ? cnd : r_cand;
+		r_len = slot ? clen : r_len;
+		if (++nev == 64)
+			publish(false);
+	};
+	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
+	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
+		const uint32_t ma = cnd + kLocalMatch, mb = base + kLocalMatch, lim = n - mb;
+		uint32_t done = 0;
+		for (;;) {
+			const uint32_t o = done + lane * 8;
+			uint32_t m8 = 0;
+			bool term = true;
+			if (o < lim) {
+				const uint64_t x = lds_rd64(win32, wbase + ma + o) ^ lds_rd64(win32, wbase + mb + o);
+				m8 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+				m8 = min(m8, lim - o);
+				term = m8 < 8 || o + 8 >= lim;
+			}
+			const uint64_t tmask = __ballot(term);
+			if (tmask) {
+				const uint32_t t = first_lane(tmask);
+				return done + 8 * t + rdlane(m8, t);
+			}
+			done += 512;
+		}
 	};
 
 	if (n >= kMargin) {
 		const uint32_t ip_limit = n - kMargin;
-		uint32_t ip = 0;       /* position right after the last copy (spec > 0) */
-		uint32_t spec = 0;     /* leading special lanes: 2 = {insert ip-1, probe ip}, 1 = {probe ip} */
+		uint32_t ip = 0;        /* position right after the last copy (spec > 0) */
+		uint32_t spec = 0;      /* leading special lanes: 2 = {insert ip-1, probe ip}, 1 = {probe ip} */
 		uint32_t s = 1, qi = 0; /* scan start and index of the next scan probe */
 		uint32_t epoch = 0x03ffffffu;
+		bool fin = false;
 
-		for (;;) {
-			/* ---- lane roles for this step ---- */
-			uint32_t pos;
-			bool valid, probing = true;
-			if (lane < spec) {
-				const uint32_t k = lane + (2 - spec); /* 0: insert ip-1, 1: probe ip */
-				pos = ip - 1 + k;
-				valid = true;
-				probing = (k == 1);
-			} else {
-				const uint32_t i = qi + lane - spec;
-				pos = scan_pos(s, i);
-				/* csnappy_compress.c:542-544: a probe happens only if the NEXT position
-				 * is still <= ip_limit */
-				valid = scan_pos(s, i + 1) <= ip_limit;
-				if (!valid)
-					pos = 0;
+		while (!fin) {
+			if (PROF) {
+				t0 = __builtin_amdgcn_s_memtime();
+				n_steps++;
 			}
-			const uint32_t w = lds_rd32(win32, wbase + pos);
-			const uint32_t h = (w * kHashMul) >> shift;
+			/* ---- lane positions ---- */
+			const bool sparse = spec == 0 && qi >= 32;
+			if (PROF && sparse)
+				n_sparse++;
+			const uint32_t p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
+			uint32_t pos;
+			bool valid;
+			if (sparse) {
+				pos = scan_pos(s, qi + lane);
+				/* csnappy_compress.c:542-544: a probe happens only if the NEXT position is
+				 * still <= ip_limit */
+				valid = scan_pos(s, qi + lane + 1) <= ip_limit;
+			} else {
+				pos = p0 + lane;
+				valid = pos + 1 <= ip_limit; /* stride-1 probes, the re-match probe and the insert */
+			}
+			if (!valid)
+				pos = 0;
+			uint32_t me[4], cb[4];
+			lds_rd128(win32, wbase + pos, me);
+			const uint32_t h = (me[0] * kHashMul) >> shift;
 			const uint32_t key = h & smask;
 			if (valid)
 				atomicMin(&S[key], (epoch << 6) | lane);
 			const uint32_t cand = tab[h];
-			__syncthreads();
+			wave_lds_fence();
 			const uint32_t first_same = S[key] & 63u; /* lowest valid lane with my slot key */
-			const uint32_t cw = lds_rd32(win32, wbase + cand);
+			lds_rd128(win32, wbase + cand, cb);
+			/* lane-local match length, capped at kLocalMatch (the end of the fragment is at least
+			 * 16 bytes away from every valid probe position) */
+			const uint64_t xlo = ((uint64_t)(me[1] ^ cb[1]) << 32) | (me[0] ^ cb[0]);
+			const uint64_t xhi = ((uint64_t)(me[3] ^ cb[3]) << 32) | (me[2] ^ cb[2]);
+			const uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
+					    : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
 			const uint64_t cmask = __ballot(valid && first_same < lane);
 			const uint64_t imask = ~__ballot(valid);
-			const uint32_t c = cmask ? first_lane(cmask) : 64; /* first lane that depends on an earlier one */
-			const uint32_t v = imask ? first_lane(imask) : 64; /* first lane past the scan limit */
-			const uint32_t ulim = min(c, v);
-			const uint64_t mmask = __ballot(lane < ulim && probing && cw == w);
+			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
+			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
+			const int ulim = min(c1, v);
+			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
 			epoch--;
+			if (PROF) {
+				t1 = __builtin_amdgcn_s_memtime();
+				t_vec += t1 - t0;
+			}
 
-			if (mmask == 0) {
-				/* no 4-byte match among the usable lanes: commit their table writes
-				 * (table[hash] = ip, csnappy_compress.c:550) and move on */
-				if (lane < ulim)
-					tab[h] = (uint16_t)pos;
-				if (ulim == v && v < 64)
-					break; /* goto emit_remainder, :543-544 */
-				if (ulim < spec) {
-					spec -= ulim;
-					s = ip + 1;
-					qi = 0;
+			uint64_t hole = 0; /* lanes strictly inside a copy: never inserted, :587-593 */
+			int e_final;
+			if (sparse) {
+				/* ---- sparse step: ends at its first match ---- */
+				if (matchmask == 0) {
+					e_final = ulim - 1;
+					if (ulim == v && v < 64)
+						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
+					else
+						qi += (uint32_t)ulim;
 				} else {
-					if (spec) {
-						s = ip + 1;
-						qi = 0;
+					const int i = (int)first_lane(matchmask);
+					e_final = i;
+					const uint32_t base = rdlane(pos, i), cnd = rdlane(cand, i);
+					uint32_t L = rdlane(mlen, i);
+					if (PROF)
+						n_match++;
+					if (L == kLocalMatch && base + L < n)
+						L += extend(cnd, base);
+					add_record(next_emit, base, cnd, L);
+					ip = base + L;
+					next_emit = ip;
+					if (ip >= ip_limit)
+						fin = true; /* :585-586 */
+					spec = 2;
+				}
+			} else {
+				/* ---- dense step: walk the chain of matches (uniform / scalar) ---- */
+				int a, zl;      /* first lane that may probe, lane of scan index 0 */
+				uint32_t seg_s; /* scan start of the current segment */
+				if (spec == 2) {
+					a = 1;
+					zl = 2;
+					seg_s = ip + 1;
+				} else if (spec == 1) {
+					a = 0;
+					zl = 1;
+					seg_s = ip + 1;
+				} else {
+					a = 0;
+					zl = -(int)qi;
+					seg_s = s;
+				}
+				int lim = zl + 31; /* last lane whose probe is still one of the 32 stride-1 probes */
+				for (;;) {
+					const uint64_t m = matchmask & ((~0ull) << a);
+					const int i = m ? (int)first_lane(m) : 64;
+					if (i > lim || i > 63) {
+						/* no match among the lanes this segment may probe */
+						const int e = min(lim, ulim - 1);
+						e_final = e;
+						if (ulim == v && v <= lim && v < 64) {
+							fin = true; /* next probe is past ip_limit: goto emit_remainder */
+						} else if (e < a) {
+							spec = 1; /* only the ip-1 insert was usable; the re-match probe is next */
+							e_final = 0;
+						} else {
+							spec = 0;
+							s = seg_s;
+							qi = (uint32_t)(e + 1 - zl);
+						}
+						break;
 					}
-					qi += ulim - spec;
-					spec = 0;
+					const uint32_t cnd = rdlane(cand, i);
+					uint32_t L = rdlane(mlen, i);
+					const uint32_t base = p0 + (uint32_t)i;
+					bool wide = false;
+					if (PROF)
+						n_match++;
+					if (L == kLocalMatch && base + L < n) {
+						wide = true;
+						if (PROF)
+							n_wide++;
+						L += extend(cnd, base);
+					}
+					add_record(next_emit, base, cnd, L);
+					ip = base + L;
+					next_emit = ip;
+					e_final = i;
+					const int c = i + (int)L; /* lane of the re-match probe */
+					if (ip >= ip_limit) {
+						fin = true; /* :585-586 */
+						break;
+					}
+					if (wide || c >= ulim) {
+						spec = 2;
+						break;
+					}
+					/* lanes i+1 .. c-2 are inside the copy; c-1 is the ip-1 insert, c the re-match probe */
+					hole |= ((1ull << (L - 2)) - 1) << (i + 1);
+					a = c;
+					zl = c + 1;
+					lim = c + 32;
+					seg_s = ip + 1;
 				}
-				continue;
 			}
-
-			const uint32_t m = first_lane(mmask);
-			if (lane <= m)
+			if (PROF) {
+				t0 = __builtin_amdgcn_s_memtime();
+				t_walk += t0 - t1;
+			}
+			/* commit table[hash] = position for every lane that was probed or inserted
+			 * (:550, :589, :593): lanes 0..e_final except the holes */
+			if ((int)lane <= e_final && !((hole >> lane) & 1))
 				tab[h] = (uint16_t)pos;
-			const uint32_t base = rdlane(pos, m);
-			const uint32_t cnd = rdlane(cand, m);
-
-			/* ---- FindMatchLength(candidate + 4, ip + 4, ip_end), :578 ---- */
-			const uint32_t ma = cnd + 4, mb = base + 4, L = n - mb;
-			uint32_t done = 0, matched;
-			for (;;) {
-				const uint32_t o = done + lane * 8;
-				uint32_t mm = 0;
-				bool term = true;
-				if (o < L) {
-					const uint64_t x = lds_rd64(win32, wbase + ma + o) ^ lds_rd64(win32, wbase + mb + o);
-					mm = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-					mm = min(mm, L - o);
-					term = mm < 8 || o + 8 >= L;
-				}
-				const uint64_t tmask = __ballot(term);
-				if (tmask) {
-					const uint32_t t = first_lane(tmask);
-					matched = 4 + done + 8 * t + rdlane(mm, t);
-					break;
-				}
-				done += 512;
-			}
-
-			/* queue {literal [next_emit, base), copy(offset, matched)} */
-			if (lane == 0) {
-				evq[2 * nev] = next_emit | ((base - next_emit) << 16);
-				evq[2 * nev + 1] = (base - cnd) | (matched << 16);
-			}
-			nev++;
-			ip = base + matched;
-			next_emit = ip;
-			if (nev == 64) {
-				__syncthreads();
-				flush();
-			}
-			if (ip >= ip_limit)
-				break; /* :585-586 */
-			spec = 2; /* :587-594: insert ip-1, probe ip; then the scan restarts at ip+1 (:596-598) */
-			s = ip + 1;
-			qi = 0;
+			wave_lds_fence();
+			if (PROF)
+				t_commit += __builtin_amdgcn_s_memtime() - t0;
 		}
 	}
 
-	/* emit_remainder, csnappy_compress.c:600-605 */
-	if (next_emit < n) {
-		if (lane == 0) {
-			evq[2 * nev] = next_emit | ((n - next_emit) << 16);
-			evq[2 * nev + 1] = 0;
-		}
-		nev++;
+	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
+	if (next_emit < n)
+		add_record(next_emit, n, n, 0);
+	publish(true);
+	if (PROF && lane == 0) {
+		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+		atomicAdd(&A.prof[0], t_end - t_begin);
+		atomicAdd(&A.prof[1], t_vec);
+		atomicAdd(&A.prof[2], t_walk);
+		atomicAdd(&A.prof[3], t_commit);
+		atomicAdd(&A.prof[4], t_pub);
+		atomicAdd(&A.prof[5], n_steps);
+		atomicAdd(&A.prof[6], n_match);
+		atomicAdd(&A.prof[7], n_wide);
+		atomicAdd(&A.prof[8], n_sparse);
+		atomicAdd(&A.prof[9], 1ull);
 	}
-	__syncthreads();
-	if (nev)
-		flush();
+}
 
-	if (lane == 0) {
-		A.frag_len[id] = op;
-		if (A.fpb == 1)
-			A.out_len[blk] = hdr + op;
-	}
+extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments(CompressArgs A)
+{
+	compress_fragment_body<false>(A);
+}
+
+/* debug instantiation with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
+extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_prof(CompressArgs A)
+{
+	compress_fragment_body<true>(A);
 }
 
 /* ==========================================================================================
@@ -684,6 +971,7 @@ struct Pending {
 	int slot;
 	hipEvent_t a, b;
 };
+unsigned long long *g_prof_buf = nullptr;
 bool g_timing = false;
 Pending g_pending[4096];
 int g_npending = 0;
@@ -731,6 +1019,13 @@ int csnappy_hip_device_count(void)
 const char *csnappy_hip_last_error(void)
 {
 	return g_last_error;
+}
+
+/* debug only (not in the public header): 16 x u64 device buffer that receives the parser's
+ * s_memtime phase counters; NULL switches back to the production kernel */
+void csnappy_hip_debug_set_profile_buffer(void *d_buf)
+{
+	g_prof_buf = static_cast<unsigned long long *>(d_buf);
 }
 
 void csnappy_hip_set_kernel_timing(int enable)
@@ -795,18 +1090,27 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.nblocks = nblocks;
 	A.fpb = fpb;
 	A.win_bytes = ((max_in_len < kFragment ? max_in_len : kFragment) + 16 + 16 + 63) & ~63u;
-	A.s_entries = (1u << (p - 1)) < 2048u ? (1u << (p - 1)) : 2048u;
+	A.s_entries = (1u << (p - 1)) < 1024u ? (1u << (p - 1)) : 1024u;
 	A.p = p;
 	A.mode = mode;
 
-	const size_t lds = (size_t)A.win_bytes + ((size_t)1 << p) + (size_t)A.s_entries * 4 + 64 * 8;
+	const size_t lds = (size_t)A.win_bytes + ((size_t)1 << p) + (size_t)A.s_entries * 4 + kRingBytes + kStageBytes;
 	if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(snappy_compress_fragments),
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+		    "hipFuncSetAttribute"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	A.prof = g_prof_buf;
+	if (g_prof_buf &&
+	    !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(snappy_compress_fragments_prof),
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
 		    "hipFuncSetAttribute"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	Timer t(st);
 	t.start();
-	hipLaunchKernelGGL(snappy_compress_fragments, dim3(nblocks * fpb), dim3(64), lds, st, A);
+	if (g_prof_buf)
+		hipLaunchKernelGGL(snappy_compress_fragments_prof, dim3(nblocks * fpb), dim3(128), lds, st, A);
+	else
+		hipLaunchKernelGGL(snappy_compress_fragments, dim3(nblocks * fpb), dim3(128), lds, st, A);
 	t.stop(0);
 	if (!hip_ok(hipGetLastError(), "launch snappy_compress_fragments"))
 		return CSNAPPY_HIP_E_RUNTIME;

@@ -374,3 +374,34 @@ def test_compact_stream_equals_concatenation(torch, urls):
     torch.cuda.synchronize()
     assert bytes(dense.cpu().numpy()) == b"".join(blocks)
     assert sha(b"".join(blocks)) == GOLD["urls_blocks"]["4k_p13"]["sha256"]
+
+
+# -------------------------------------------------------------------------------------------------
+# BASELINE config #1: the reference's only end-to-end test (reference Makefile:21-29) on the HIP
+# path, through the plain-C CLI built from tools/snappy_cli.c against include/csnappy.h
+# -------------------------------------------------------------------------------------------------
+def _cli(args, data=b""):
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "tools", "cl_tester")
+    return subprocess.run([exe] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+
+
+def test_cl_tester_round_trip_and_selftests(torch, urls, golden_dir, tmp_path):
+    # cl_tester -c < urls.10K | cl_tester -d -c == urls.10K ; default power 16 like the reference
+    c = _cli(["-c"], urls)
+    assert c.returncode == 0
+    assert len(c.stdout) == GOLD["urls_whole"]["16"]["size"] and sha(c.stdout) == GOLD["urls_whole"]["16"]["sha256"]
+    d = _cli(["-d", "-c"], c.stdout)
+    assert d.returncode == 0 and d.stdout == urls
+    # -p 15 reproduces the reference's shipped testdata/urls.10K.snappy
+    shipped = open(os.path.join(golden_dir, "urls.10K.snappy"), "rb").read()
+    assert _cli(["-p", "15", "-c"], urls).stdout == shipped
+    # file form + the malformed fixture: exit code 7 like the reference ("snappy_decompress returned -5")
+    bad = _cli(["-d", os.path.join(golden_dir, "baddata3.snappy"), str(tmp_path / "out")])
+    assert bad.returncode == 7 and b"returned -5" in bad.stderr
+    # -S d: "decompression is safe" (-2, -3 next to a guard page, cut-off literal is an error)
+    sd = _cli(["-S", "d"])
+    assert sd.returncode == 0, sd.stderr
+    # -S c: the compressor does not bounds-check its output; the reference expects the fault
+    sc = _cli(["-S", "c"])
+    assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)

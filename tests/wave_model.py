@@ -133,3 +133,149 @@ def compress_fragment(F, p, s_entries=None, stats=None):
     if next_emit < n:
         records.append((next_emit, n - next_emit, 0, 0))
     return encode_records(F, records)
+
+
+# =================================================================================================
+# v2: dense multi-match steps.  A dense step lays 64 CONSECUTIVE positions on the lanes, every
+# lane computes its candidate and a lane-local match length (capped at LM), and the true chain of
+# matches through the step is then walked (on the GPU: on the scalar unit).  Sparse steps (the v1
+# layout) are used only once a scan has made 32 probes without a match (stride >= 2).
+# =================================================================================================
+LM = 16
+
+
+def compress_fragment_v2(F, p, s_entries=None, stats=None, lm=LM):
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 64
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    if s_entries is None:
+        s_entries = min(1 << (p - 1), 2048)
+    smask = s_entries - 1
+    records = []
+    next_emit = 0
+
+    def lcp(a, b, start, limit):
+        k = start
+        while k < limit and F[a + k] == F[b + k]:
+            k += 1
+        return k
+
+    if n >= MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        ip, spec, s, qi = 0, 0, 1, 0
+        done = False
+        while not done:
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            sparse = spec == 0 and qi >= 32
+            if stats is not None and sparse:
+                stats["sparse"] = stats.get("sparse", 0) + 1
+            # ---- lane positions / validity ------------------------------------------------------
+            pos, valid = [0] * WAVE, [False] * WAVE
+            if sparse:
+                for l in range(WAVE):
+                    pos[l] = scan_pos(s, qi + l)
+                    valid[l] = scan_pos(s, qi + l + 1) <= ip_limit
+            else:
+                p0 = ip - 1 if spec == 2 else ip if spec == 1 else s + qi
+                for l in range(WAVE):
+                    pos[l] = p0 + l
+                    valid[l] = pos[l] + 1 <= ip_limit
+            for l in range(WAVE):
+                if not valid[l]:
+                    pos[l] = 0
+            w = [rd32(pos[l]) for l in range(WAVE)]
+            h = [((w[l] * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            key = [h[l] & smask for l in range(WAVE)]
+            first = {}
+            for l in range(WAVE):
+                if valid[l] and key[l] not in first:
+                    first[key[l]] = l
+            cand = [tab[h[l]] for l in range(WAVE)]
+            c_ = next((l for l in range(WAVE) if valid[l] and first[key[l]] < l), 64)
+            v = next((l for l in range(WAVE) if not valid[l]), 64)
+            ulim = min(c_, v)
+
+            if sparse:
+                cw = [rd32(cand[l]) for l in range(WAVE)]
+                m = next((l for l in range(ulim) if cw[l] == w[l]), None)
+                if m is None:
+                    for l in range(ulim):
+                        tab[h[l]] = pos[l]
+                    if ulim == v and v < 64:
+                        break
+                    qi += ulim
+                    continue
+                for l in range(m + 1):
+                    tab[h[l]] = pos[l]
+                base, cnd = pos[m], cand[m]
+                matched = lcp(cnd, base, 4, n - base)
+                records.append((next_emit, base - next_emit, base - cnd, matched))
+                ip = base + matched
+                next_emit = ip
+                if ip >= ip_limit:
+                    break
+                spec, s, qi = 2, ip + 1, 0
+                continue
+
+            # ---- dense step ------------------------------------------------------------------------
+            mlen = [lcp(cand[l], pos[l], 0, min(lm, n - pos[l])) if valid[l] else 0 for l in range(WAVE)]
+            ins = set()
+            if spec == 2:
+                a, zlane = 1, 2
+                if ulim >= 1:
+                    ins.add(0)
+            elif spec == 1:
+                a, zlane = 0, 1
+            else:
+                a, zlane = 0, -qi
+            seg_s = ip + 1 if spec else s
+            while True:
+                seg_end = zlane + 31
+                e = min(seg_end, ulim - 1, 63)
+                i = next((l for l in range(a, e + 1) if mlen[l] >= 4), None)
+                if i is None:
+                    for l in range(a, e + 1):
+                        ins.add(l)
+                    if e + 1 == v and v == ulim and v <= min(seg_end, 63):
+                        done = True  # the next probe is past ip_limit: emit_remainder
+                        break
+                    if e < a and a == 1 and zlane == 2 and e == 0:
+                        # only the insert lane was usable (rematch lane shares its slot)
+                        spec = 1
+                        break
+                    if e < a:
+                        # cannot happen for chained segments (c < ulim is required to chain) nor for
+                        # spec 0/1 starts (lane 0 is never conflicted; invalid lane 0 handled above)
+                        raise AssertionError((a, e, ulim, v, spec))
+                    spec, s, qi = 0, seg_s, e + 1 - zlane
+                    break
+                for l in range(a, i + 1):
+                    ins.add(l)
+                base, cnd, L = pos[i], cand[i], mlen[i]
+                wide = False
+                if L == lm and base + L < n:
+                    L = lcp(cnd, base, lm, n - base)
+                    wide = True
+                records.append((next_emit, base - next_emit, base - cnd, L))
+                ip = base + L
+                next_emit = ip
+                if ip >= ip_limit:
+                    done = True
+                    break
+                c = ip - pos[0] if valid[0] else None
+                if wide or c is None or c > 63 or c >= ulim:
+                    spec, s, qi = 2, ip + 1, 0
+                    break
+                ins.add(c - 1)
+                a, zlane, seg_s = c, c + 1, ip + 1
+                if stats is not None:
+                    stats["chained"] = stats.get("chained", 0) + 1
+            for l in ins:
+                tab[h[l]] = pos[l]
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
