@@ -474,16 +474,15 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
-	/* records of the current batch live in four VGPRs, record r in lane r */
-	uint32_t r_lit = 0, r_base = 0, r_cand = 0, r_len = 0;
-	uint32_t nev = 0, batch = 0;
-	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
+	uint4 *ring4 = reinterpret_cast<uint4 *>(ring);
+	uint32_t nev = 0, batch = 0; /* records queued in the current batch */
+	uint32_t next_emit = 0;      /* csnappy_compress.c:496 */
+	const uint64_t lt_mask = (1ull << lane) - 1;
 
 	auto publish = [&](bool last) {
 		unsigned long long tp = 0;
 		if (PROF)
 			tp = __builtin_amdgcn_s_memtime();
-		reinterpret_cast<uint4 *>(ring)[batch * 64 + lane] = make_uint4(r_lit, r_base, r_cand, r_len);
 		if (lane == 0)
 			ring_cnt[batch] = nev | (last ? 0x10000u : 0u);
 		__syncthreads();
@@ -492,12 +491,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		if (PROF)
 			t_pub += __builtin_amdgcn_s_memtime() - tp;
 	};
+	/* one record produced by uniform code: {literal [lit_start, base), copy(base - cnd, clen)} */
 	auto add_record = [&](uint32_t lit_start, uint32_t base, uint32_t cnd, uint32_t clen) {
-		const bool slot = lane == nev;
-		r_lit = slot ? lit_start : r_lit;
-		r_base = slot ? base : r_base;
-		r_cand = slot ? cnd : r_cand;
-		r_len = slot ? clen : r_len;
+		if (lane == 0)
+			ring4[batch * 64 + nev] = make_uint4(lit_start, base, cnd, clen);
 		if (++nev == 64)
 			publish(false);
 	};
@@ -532,18 +529,16 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		uint32_t epoch = 0x03ffffffu;
 		bool fin = false;
 
-		while (!fin) {
-			if (PROF) {
-				t0 = __builtin_amdgcn_s_memtime();
-				n_steps++;
-			}
-			/* ---- lane positions ---- */
-			const bool sparse = spec == 0 && qi >= 32;
-			if (PROF && sparse)
-				n_sparse++;
-			const uint32_t p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
-			uint32_t pos;
-			bool valid;
+		/* lane positions of a step; the 16 bytes at the lane's position are fetched one step
+		 * ahead (as soon as the cursor of the next step is known) to take that LDS round trip
+		 * off the dependent chain */
+		bool sparse;
+		uint32_t p0, pos;
+		bool valid;
+		uint32_t me[4];
+		auto place = [&]() {
+			sparse = spec == 0 && qi >= 32;
+			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
 			if (sparse) {
 				pos = scan_pos(s, qi + lane);
 				/* csnappy_compress.c:542-544: a probe happens only if the NEXT position is
@@ -555,11 +550,26 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			if (!valid)
 				pos = 0;
-			uint32_t me[4], cb[4];
 			lds_rd128(win32, wbase + pos, me);
-			const uint32_t h = (me[0] * kHashMul) >> shift;
+		};
+		place();
+
+		while (!fin) {
+			if (PROF) {
+				t0 = __builtin_amdgcn_s_memtime();
+				n_steps++;
+				if (sparse)
+					n_sparse++;
+			}
+			/* this step's lane state (the next step's is placed before the step ends) */
+			const bool sparse_c = sparse;
+			const uint32_t p0_c = p0, pos_c = pos;
+			const bool valid_c = valid;
+			uint32_t cb[4];
+			const uint32_t me0 = me[0], me1 = me[1], me2 = me[2], me3 = me[3];
+			const uint32_t h = (me0 * kHashMul) >> shift;
 			const uint32_t key = h & smask;
-			if (valid)
+			if (valid_c)
 				atomicMin(&S[key], (epoch << 6) | lane);
 			const uint32_t cand = tab[h];
 			wave_lds_fence();
@@ -567,12 +577,12 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			lds_rd128(win32, wbase + cand, cb);
 			/* lane-local match length, capped at kLocalMatch (the end of the fragment is at least
 			 * 16 bytes away from every valid probe position) */
-			const uint64_t xlo = ((uint64_t)(me[1] ^ cb[1]) << 32) | (me[0] ^ cb[0]);
-			const uint64_t xhi = ((uint64_t)(me[3] ^ cb[3]) << 32) | (me[2] ^ cb[2]);
+			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
+			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
 			const uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
 					    : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
-			const uint64_t cmask = __ballot(valid && first_same < lane);
-			const uint64_t imask = ~__ballot(valid);
+			const uint64_t cmask = __ballot(valid_c && first_same < lane);
+			const uint64_t imask = ~__ballot(valid_c);
 			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
 			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
 			const int ulim = min(c1, v);
@@ -583,9 +593,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				t_vec += t1 - t0;
 			}
 
-			uint64_t hole = 0; /* lanes strictly inside a copy: never inserted, :587-593 */
-			int e_final;
-			if (sparse) {
+			int e_final;            /* last lane whose table write is committed */
+			bool inside = false;    /* dense: this lane lies strictly inside a taken copy */
+			uint64_t taken = 0;     /* dense: lanes whose match is part of the chain */
+			const uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
+			const uint32_t emit0 = next_emit;
+			const uint32_t nev0 = nev;
+			if (sparse_c) {
 				/* ---- sparse step: ends at its first match ---- */
 				if (matchmask == 0) {
 					e_final = ulim - 1;
@@ -596,7 +610,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				} else {
 					const int i = (int)first_lane(matchmask);
 					e_final = i;
-					const uint32_t base = rdlane(pos, i), cnd = rdlane(cand, i);
+					const uint32_t base = rdlane(pos_c, i), cnd = rdlane(cand, i);
 					uint32_t L = rdlane(mlen, i);
 					if (PROF)
 						n_match++;
@@ -609,8 +623,21 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 						fin = true; /* :585-586 */
 					spec = 2;
 				}
+				if (!fin)
+					place();
 			} else {
-				/* ---- dense step: walk the chain of matches (uniform / scalar) ---- */
+				/* ---- dense step ----
+				 * nx = the next match lane of the chain if my match is taken:
+				 *      64 -> the re-match probe falls outside the usable lanes (step ends, spec 2)
+				 *      65 -> none of the 33 probes after my match (re-match + 32 scan) matches */
+				uint32_t nx;
+				{
+					const uint64_t rest = cl < 64 ? matchmask >> cl : 0;
+					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					const uint32_t j = cl + fm;
+					nx = (int)cl >= ulim ? 64u : (fm <= 32 && j <= 63) ? j : 65u;
+				}
+				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
 				int a, zl;      /* first lane that may probe, lane of scan index 0 */
 				uint32_t seg_s; /* scan start of the current segment */
 				if (spec == 2) {
@@ -627,66 +654,114 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 					seg_s = s;
 				}
 				int lim = zl + 31; /* last lane whose probe is still one of the 32 stride-1 probes */
-				for (;;) {
-					const uint64_t m = matchmask & ((~0ull) << a);
-					const int i = m ? (int)first_lane(m) : 64;
-					if (i > lim || i > 63) {
-						/* no match among the lanes this segment may probe */
-						const int e = min(lim, ulim - 1);
-						e_final = e;
-						if (ulim == v && v <= lim && v < 64) {
-							fin = true; /* next probe is past ip_limit: goto emit_remainder */
-						} else if (e < a) {
-							spec = 1; /* only the ip-1 insert was usable; the re-match probe is next */
-							e_final = 0;
-						} else {
-							spec = 0;
-							s = seg_s;
-							qi = (uint32_t)(e + 1 - zl);
+				const uint64_t m0 = matchmask & ((~0ull) << a);
+				int i = m0 ? (int)first_lane(m0) : 64;
+				int last = -1;
+				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
+				if (i <= lim && i <= 63) {
+					for (;;) {
+						if ((widemask >> i) & 1) {
+							stop = 66;
+							break;
 						}
-						break;
+						taken |= 1ull << i;
+						last = i;
+						const uint32_t t = rdlane(nx, i);
+						if (t >= 64) {
+							stop = t;
+							break;
+						}
+						i = (int)t;
 					}
-					const uint32_t cnd = rdlane(cand, i);
-					uint32_t L = rdlane(mlen, i);
-					const uint32_t base = p0 + (uint32_t)i;
-					bool wide = false;
-					if (PROF)
-						n_match++;
-					if (L == kLocalMatch && base + L < n) {
-						wide = true;
-						if (PROF)
-							n_wide++;
-						L += extend(cnd, base);
-					}
-					add_record(next_emit, base, cnd, L);
-					ip = base + L;
-					next_emit = ip;
-					e_final = i;
-					const int c = i + (int)L; /* lane of the re-match probe */
-					if (ip >= ip_limit) {
-						fin = true; /* :585-586 */
-						break;
-					}
-					if (wide || c >= ulim) {
-						spec = 2;
-						break;
-					}
-					/* lanes i+1 .. c-2 are inside the copy; c-1 is the ip-1 insert, c the re-match probe */
-					hole |= ((1ull << (L - 2)) - 1) << (i + 1);
-					a = c;
-					zl = c + 1;
-					lim = c + 32;
-					seg_s = ip + 1;
 				}
+				if (last >= 0) {
+					const int c_last = (int)rdlane(cl, last);
+					ip = p0_c + (uint32_t)c_last;
+					next_emit = ip;
+					a = c_last;
+					zl = c_last + 1;
+					lim = c_last + 32;
+					seg_s = ip + 1;
+					if (PROF)
+						n_match += __builtin_popcountll(taken);
+				}
+				uint32_t wbase_l = 0, wcnd = 0;
+				if (stop == 66) {
+					/* a match longer than the lane-local cap: extend it wave-wide; it ends the step */
+					wbase_l = p0_c + (uint32_t)i;
+					wcnd = rdlane(cand, i);
+					const uint32_t L = kLocalMatch + extend(wcnd, wbase_l);
+					e_final = i;
+					ip = wbase_l + L;
+					if (PROF) {
+						n_match++;
+						n_wide++;
+					}
+					spec = 2;
+					if (ip >= ip_limit)
+						fin = true;
+				} else if (stop == 64) {
+					e_final = last;
+					spec = 2;
+					if (ip >= ip_limit)
+						fin = true; /* :585-586 */
+				} else {
+					/* 65 / 67: the current segment (a, zl, lim, seg_s) has no match */
+					const int e = min(lim, ulim - 1);
+					e_final = e;
+					if (ulim == v && v <= lim && v < 64) {
+						fin = true; /* next probe is past ip_limit: goto emit_remainder */
+					} else if (e < a) {
+						spec = 1; /* only the ip-1 insert was usable; the re-match probe is next */
+						e_final = 0;
+					} else {
+						spec = 0;
+						s = seg_s;
+						qi = (uint32_t)(e + 1 - zl);
+					}
+				}
+				const uint32_t emit1 = next_emit; /* literal start of a wide record */
+				if (stop == 66)
+					next_emit = ip;
+				/* the cursor of the next step is known: fetch its bytes now */
+				if (!fin)
+					place();
+
+				/* ---- records of the taken matches, built by their own lanes ---- */
+				if (taken) {
+					const uint64_t below = taken & lt_mask;
+					const bool hasprev = below != 0;
+					const uint32_t jprev = hasprev ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+					const bool mine = (taken >> lane) & 1;
+					const uint32_t lit_start = hasprev ? p0_c + cprev : emit0;
+					inside = hasprev && lane + 1 < cprev; /* strictly inside a taken copy: never inserted */
+					const uint32_t idx = nev0 + (uint32_t)__builtin_popcountll(below);
+					const uint32_t ntaken = (uint32_t)__builtin_popcountll(taken);
+					const uint4 rec = make_uint4(lit_start, p0_c + lane, cand, mlen);
+					if (mine && idx < 64)
+						ring4[batch * 64 + idx] = rec;
+					if (nev0 + ntaken >= 64) {
+						nev = 64;
+						publish(false);
+						if (mine && idx >= 64)
+							ring4[batch * 64 + idx - 64] = rec;
+						nev = nev0 + ntaken - 64;
+					} else {
+						nev = nev0 + ntaken;
+					}
+				}
+				if (stop == 66)
+					add_record(emit1, wbase_l, wcnd, ip - wbase_l);
 			}
 			if (PROF) {
 				t0 = __builtin_amdgcn_s_memtime();
 				t_walk += t0 - t1;
 			}
 			/* commit table[hash] = position for every lane that was probed or inserted
-			 * (:550, :589, :593): lanes 0..e_final except the holes */
-			if ((int)lane <= e_final && !((hole >> lane) & 1))
-				tab[h] = (uint16_t)pos;
+			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
+			if ((int)lane <= e_final && !inside)
+				tab[h] = (uint16_t)pos_c;
 			wave_lds_fence();
 			if (PROF)
 				t_commit += __builtin_amdgcn_s_memtime() - t0;
