@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/csnappy.h"
@@ -62,6 +63,8 @@ struct CompressArgs {
 	int p;
 	int mode;
 	unsigned long long *prof; /* debug cycle counters (PROF instantiation only) */
+	uint16_t *gtab;   /* GTAB instantiation: one 2^p-byte hash table per workgroup of the launch */
+	uint32_t id_base; /* first fragment id of this launch (launches are chunked in GTAB mode) */
 };
 
 struct DecompressArgs {
@@ -195,7 +198,7 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  *                step ends at its first match.
  * ======================================================================================== */
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
-constexpr uint32_t kBigRecord = 64;   /* records encoding to more than this bypass the staging */
+constexpr uint32_t kBigRecord = 40;   /* records encoding to more than this bypass the staging */
 constexpr uint32_t kFlushAt = 512;   /* staged bytes that trigger a coalesced flush */
 constexpr uint32_t kStageBytes = 16 + kFlushAt + 64 * kBigRecord + 16; /* LDS output staging */
 constexpr uint32_t kRingBytes = 2 * 64 * 16 + 16; /* two batches of 64 records (4 dwords each) + two count words */
@@ -224,14 +227,14 @@ DEVINL void wave_lds_fence()
 	__builtin_amdgcn_wave_barrier();
 }
 
-template <bool PROF>
+template <bool PROF, bool GTAB>
 __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t role = tid >> 6; /* 0 = parser, 1 = emitter (wave-uniform) */
-	const uint32_t id = blockIdx.x;
+	const uint32_t id = blockIdx.x + A.id_base;
 	const uint32_t blk = id / A.fpb, fi = id - blk * A.fpb;
 	const uint32_t len = A.in_len[blk];
 	const uint32_t foff = fi * kFragment;
@@ -242,11 +245,14 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	const uint32_t shift = 33 - ws;
 	const uint8_t *src = A.in + A.in_off[blk] + foff;
 
-	/* ---- LDS carve: window | hash table | conflict scratch | record ring | output staging ---- */
+	/* ---- LDS carve: window | hash table | conflict scratch | record ring | output staging ----
+	 * GTAB: the hash table lives in global memory (L2 / Infinity Cache resident: one private 2^p
+	 * bytes per workgroup of the launch) so that four fragments fit a CU's LDS instead of one. */
 	uint32_t *win32 = reinterpret_cast<uint32_t *>(smem);
 	uint8_t *win8 = smem;
-	uint16_t *tab = reinterpret_cast<uint16_t *>(smem + A.win_bytes);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.win_bytes + (1u << A.p));
+	uint16_t *tab = GTAB ? A.gtab + ((uint64_t)blockIdx.x << (A.p - 1))
+			     : reinterpret_cast<uint16_t *>(smem + A.win_bytes);
+	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.win_bytes + (GTAB ? 0u : (1u << A.p)));
 	uint32_t *ring = S + A.s_entries;       /* [2][64] records {lit_start, base, cand, copy_len} */
 	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
 	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
@@ -535,7 +541,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		bool sparse;
 		uint32_t p0, pos;
 		bool valid;
-		uint32_t me[4];
+		uint32_t raw[5], rsh = 0; /* the five aligned dwords that cover the lane's 16 bytes */
 		auto place = [&]() {
 			sparse = spec == 0 && qi >= 32;
 			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
@@ -550,7 +556,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			if (!valid)
 				pos = 0;
-			lds_rd128(win32, wbase + pos, me);
+			rsh = wbase + pos;
+			const uint32_t d = rsh >> 2;
+			raw[0] = win32[d];
+			raw[1] = win32[d + 1];
+			raw[2] = win32[d + 2];
+			raw[3] = win32[d + 3];
+			raw[4] = win32[d + 4];
 		};
 		place();
 
@@ -566,7 +578,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t p0_c = p0, pos_c = pos;
 			const bool valid_c = valid;
 			uint32_t cb[4];
-			const uint32_t me0 = me[0], me1 = me[1], me2 = me[2], me3 = me[3];
+			const uint32_t me0 = __builtin_amdgcn_alignbyte(raw[1], raw[0], rsh);
+			const uint32_t me1 = __builtin_amdgcn_alignbyte(raw[2], raw[1], rsh);
+			const uint32_t me2 = __builtin_amdgcn_alignbyte(raw[3], raw[2], rsh);
+			const uint32_t me3 = __builtin_amdgcn_alignbyte(raw[4], raw[3], rsh);
 			const uint32_t h = (me0 * kHashMul) >> shift;
 			const uint32_t key = h & smask;
 			if (valid_c)
@@ -789,13 +804,24 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments(CompressArgs A)
 {
-	compress_fragment_body<false>(A);
+	compress_fragment_body<false, false>(A);
 }
 
-/* debug instantiation with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
+/* hash table in global memory (more fragments per CU when the table would fill the LDS) */
+extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab(CompressArgs A)
+{
+	compress_fragment_body<false, true>(A);
+}
+
+/* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_prof(CompressArgs A)
 {
-	compress_fragment_body<true>(A);
+	compress_fragment_body<true, false>(A);
+}
+
+extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab_prof(CompressArgs A)
+{
+	compress_fragment_body<true, true>(A);
 }
 
 /* ==========================================================================================
@@ -1074,6 +1100,33 @@ struct Timer {
 	}
 };
 
+constexpr uint32_t kMaxGlobalTables = 16384; /* fragments per launch in global-table mode */
+
+constexpr uint32_t kLdsPerCu = 160 * 1024;
+
+size_t compress_lds_bytes(uint32_t win_bytes, int p, bool gtab, uint32_t *s_entries)
+{
+	const uint32_t s_cap = gtab ? 512u : 1024u;
+	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
+	return (size_t)win_bytes + (gtab ? 0 : ((size_t)1 << p)) + (size_t)*s_entries * 4 + kRingBytes + kStageBytes;
+}
+
+/* Where the hash table lives.  In LDS it is one round trip closer, but with a 32 KiB window it
+ * leaves room for only 1-3 fragments per CU; in global memory (L2 / Infinity Cache resident)
+ * four fragments fit.  Measured on MI355X (tools/mode_matrix.py): global wins whenever the LDS
+ * form fits fewer than four workgroups per CU, LDS wins for 4 KiB pages (7 per CU).
+ * CSNAPPY_HIP_TABLE=lds|global overrides the choice (experiments). */
+bool use_global_table(uint32_t win_bytes, int p)
+{
+	const char *e = getenv("CSNAPPY_HIP_TABLE");
+	if (e && !strcmp(e, "global"))
+		return true;
+	if (e && !strcmp(e, "lds"))
+		return false;
+	uint32_t se;
+	return kLdsPerCu / compress_lds_bytes(win_bytes, p, false, &se) < 4;
+}
+
 uint32_t frags_per_block(uint32_t max_in_len)
 {
 	return max_in_len ? (max_in_len + kFragment - 1) / kFragment : 1;
@@ -1130,7 +1183,10 @@ size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len
 {
 	const uint64_t fpb = frags_per_block(max_in_len);
 	const uint64_t fl = ((uint64_t)nblocks * fpb * sizeof(uint32_t) + 255) & ~255ull;
-	return (size_t)(fl + (uint64_t)nblocks * (fpb - 1) * kScratchSlot + 256);
+	const uint64_t stagebytes = ((uint64_t)nblocks * (fpb - 1) * kScratchSlot + 65535) & ~65535ull;
+	/* global-memory hash tables (table mode "global"): one 64 KiB table per fragment in flight */
+	const uint64_t tabs = (uint64_t)nblocks * fpb < kMaxGlobalTables ? (uint64_t)nblocks * fpb : kMaxGlobalTables;
+	return (size_t)(fl + stagebytes + tabs * 65536 + 65536);
 }
 
 int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
@@ -1165,27 +1221,38 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.nblocks = nblocks;
 	A.fpb = fpb;
 	A.win_bytes = ((max_in_len < kFragment ? max_in_len : kFragment) + 16 + 16 + 63) & ~63u;
-	A.s_entries = (1u << (p - 1)) < 1024u ? (1u << (p - 1)) : 1024u;
+	const bool gtab = use_global_table(A.win_bytes, p);
+	const size_t lds = compress_lds_bytes(A.win_bytes, p, gtab, &A.s_entries);
 	A.p = p;
 	A.mode = mode;
-
-	const size_t lds = (size_t)A.win_bytes + ((size_t)1 << p) + (size_t)A.s_entries * 4 + kRingBytes + kStageBytes;
-	if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(snappy_compress_fragments),
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-		    "hipFuncSetAttribute"))
-		return CSNAPPY_HIP_E_RUNTIME;
 	A.prof = g_prof_buf;
-	if (g_prof_buf &&
-	    !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(snappy_compress_fragments_prof),
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+	const uint64_t stagebytes = ((uint64_t)nblocks * (fpb - 1) * kScratchSlot + 65535) & ~65535ull;
+	{
+		/* table region: 64 KiB aligned */
+		uintptr_t t = reinterpret_cast<uintptr_t>(A.scratch) + stagebytes;
+		t = (t + 65535) & ~(uintptr_t)65535;
+		A.gtab = reinterpret_cast<uint16_t *>(t);
+	}
+	A.id_base = 0;
+
+	const void *kfn = gtab ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_compress_fragments_gtab_prof)
+					     : reinterpret_cast<const void *>(snappy_compress_fragments_gtab))
+			       : (g_prof_buf ? reinterpret_cast<const void *>(snappy_compress_fragments_prof)
+					     : reinterpret_cast<const void *>(snappy_compress_fragments));
+	if (!hip_ok(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
 		    "hipFuncSetAttribute"))
 		return CSNAPPY_HIP_E_RUNTIME;
+	const uint32_t total = nblocks * fpb;
+	const uint32_t per_launch = gtab ? kMaxGlobalTables : total;
 	Timer t(st);
 	t.start();
-	if (g_prof_buf)
-		hipLaunchKernelGGL(snappy_compress_fragments_prof, dim3(nblocks * fpb), dim3(128), lds, st, A);
-	else
-		hipLaunchKernelGGL(snappy_compress_fragments, dim3(nblocks * fpb), dim3(128), lds, st, A);
+	for (uint32_t base = 0; base < total; base += per_launch) {
+		const uint32_t cnt = total - base < per_launch ? total - base : per_launch;
+		A.id_base = base;
+		void *args[] = { &A };
+		if (!hip_ok(hipLaunchKernel(kfn, dim3(cnt), dim3(128), args, lds, st), "launch snappy_compress_fragments"))
+			return CSNAPPY_HIP_E_RUNTIME;
+	}
 	t.stop(0);
 	if (!hip_ok(hipGetLastError(), "launch snappy_compress_fragments"))
 		return CSNAPPY_HIP_E_RUNTIME;
