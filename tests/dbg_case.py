@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # debug helper, run from the repo root
 import numpy as np, oracle
 from csnappy_amd import api
 P = oracle.best()
