@@ -184,7 +184,7 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  * stores.  The two waves meet at one s_barrier per 64 records (double-buffered ring).
  *
  * Step logic (restated lane by lane in tests/wave_model.py::compress_fragment_v2 and fuzzed
- * against the CPU checker in tests/test_oracle.py):
+ * against the CPU checker):
  *   dense step   the 64 lanes take 64 CONSECUTIVE positions starting at the cursor.  Every lane
  *                hashes its 4 bytes, gathers table[h], and computes a lane-local match length
  *                (up to kLocalMatch bytes) against its candidate.  The step is truncated at the
