@@ -106,6 +106,28 @@ DEVINL uint64_t lds_rd64(const uint32_t *w, uint32_t byte)
 	return ((uint64_t)hi << 32) | lo;
 }
 
+/* Window readers.  G = the window is the input itself in global memory (unaligned vector loads);
+ * otherwise it is the LDS copy (aligned dwords + v_alignbyte). */
+template <bool G> DEVINL uint32_t win_rd32(const uint32_t *w, uint32_t byte)
+{
+	if (G) {
+		uint32_t v;
+		__builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(w) + byte, 4);
+		return v;
+	}
+	return lds_rd32(w, byte);
+}
+
+template <bool G> DEVINL uint64_t win_rd64(const uint32_t *w, uint32_t byte)
+{
+	if (G) {
+		uint64_t v;
+		__builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(w) + byte, 8);
+		return v;
+	}
+	return lds_rd64(w, byte);
+}
+
 /* exclusive prefix sum across the 64 lanes; *total receives the wave sum */
 DEVINL uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t *total)
 {
@@ -227,7 +249,7 @@ DEVINL void wave_lds_fence()
 	__builtin_amdgcn_wave_barrier();
 }
 
-template <bool PROF, bool GTAB>
+template <bool PROF, bool GTAB, bool GWIN>
 __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -248,19 +270,23 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	/* ---- LDS carve: window | hash table | conflict scratch | record ring | output staging ----
 	 * GTAB: the hash table lives in global memory (L2 / Infinity Cache resident: one private 2^p
 	 * bytes per workgroup of the launch) so that four fragments fit a CU's LDS instead of one. */
-	uint32_t *win32 = reinterpret_cast<uint32_t *>(smem);
-	uint8_t *win8 = smem;
+	/* GWIN: the window is not staged at all: the parser and the emitter read the input where it
+	 * lies (L1/L2), which leaves ~8 KiB of LDS per fragment and lets 16 fragments share a CU. */
+	const uint32_t wbase = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+	const uint32_t wlds = GWIN ? 0u : A.win_bytes;
+	const uint32_t *win32 = GWIN ? reinterpret_cast<const uint32_t *>(src - wbase)
+				     : reinterpret_cast<const uint32_t *>(smem);
+	const uint8_t *win8 = reinterpret_cast<const uint8_t *>(win32);
 	uint16_t *tab = GTAB ? A.gtab + ((uint64_t)blockIdx.x << (A.p - 1))
-			     : reinterpret_cast<uint16_t *>(smem + A.win_bytes);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.win_bytes + (GTAB ? 0u : (1u << A.p)));
+			     : reinterpret_cast<uint16_t *>(smem + wlds);
+	uint32_t *S = reinterpret_cast<uint32_t *>(smem + wlds + (GTAB ? 0u : (1u << A.p)));
 	uint32_t *ring = S + A.s_entries;       /* [2][64] records {lit_start, base, cand, copy_len} */
 	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
 	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
 	const uint32_t smask = A.s_entries - 1;
 
 	/* window: aligned 16 B chunks; byte i of the fragment sits at win8[wbase + i] */
-	const uint32_t wbase = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
-	{
+	if (!GWIN) {
 		const uint4 *g = reinterpret_cast<const uint4 *>(src - wbase);
 		uint4 *l = reinterpret_cast<uint4 *>(smem);
 		const uint32_t chunks = (wbase + n + 15) >> 4;
@@ -434,7 +460,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 					const uint32_t words = (ll - head) >> 2;
 					uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
 					for (uint32_t k = lane; k < words; k += 64)
-						d32[k] = lds_rd32(win32, wbase + ls + head + 4 * k);
+						d32[k] = win_rd32<GWIN>(win32, wbase + ls + head + 4 * k);
 					const uint32_t t0 = head + 4 * words;
 					if (t0 + lane < ll)
 						d[t0 + lane] = win8[wbase + ls + t0 + lane];
@@ -513,10 +539,17 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			uint32_t m8 = 0;
 			bool term = true;
 			if (o < lim) {
-				const uint64_t x = lds_rd64(win32, wbase + ma + o) ^ lds_rd64(win32, wbase + mb + o);
-				m8 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-				m8 = min(m8, lim - o);
-				term = m8 < 8 || o + 8 >= lim;
+				if (GWIN && o + 8 > lim) {
+					/* the last few bytes of the fragment: never read past the input */
+					while (m8 < lim - o && win8[wbase + ma + o + m8] == win8[wbase + mb + o + m8])
+						++m8;
+					term = true;
+				} else {
+					const uint64_t x = win_rd64<GWIN>(win32, wbase + ma + o) ^ win_rd64<GWIN>(win32, wbase + mb + o);
+					m8 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+					m8 = min(m8, lim - o);
+					term = m8 < 8 || o + 8 >= lim;
+				}
 			}
 			const uint64_t tmask = __ballot(term);
 			if (tmask) {
@@ -557,12 +590,23 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			if (!valid)
 				pos = 0;
 			rsh = wbase + pos;
-			const uint32_t d = rsh >> 2;
-			raw[0] = win32[d];
-			raw[1] = win32[d + 1];
-			raw[2] = win32[d + 2];
-			raw[3] = win32[d + 3];
-			raw[4] = win32[d + 4];
+			if (GWIN) {
+				uint4 v; /* valid lanes have 16 bytes of fragment at pos (pos <= n - 16) */
+				__builtin_memcpy(&v, win8 + rsh, 16);
+				raw[0] = v.x;
+				raw[1] = v.y;
+				raw[2] = v.z;
+				raw[3] = v.w;
+				raw[4] = 0;
+				rsh = 0;
+			} else {
+				const uint32_t d = rsh >> 2;
+				raw[0] = win32[d];
+				raw[1] = win32[d + 1];
+				raw[2] = win32[d + 2];
+				raw[3] = win32[d + 3];
+				raw[4] = win32[d + 4];
+			}
 		};
 		place();
 
@@ -589,7 +633,16 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t cand = tab[h];
 			wave_lds_fence();
 			const uint32_t first_same = S[key] & 63u; /* lowest valid lane with my slot key */
-			lds_rd128(win32, wbase + cand, cb);
+			if (GWIN) {
+				uint4 v; /* cand < pos, so these 16 bytes are inside the fragment too */
+				__builtin_memcpy(&v, win8 + wbase + cand, 16);
+				cb[0] = v.x;
+				cb[1] = v.y;
+				cb[2] = v.z;
+				cb[3] = v.w;
+			} else {
+				lds_rd128(win32, wbase + cand, cb);
+			}
 			/* lane-local match length, capped at kLocalMatch (the end of the fragment is at least
 			 * 16 bytes away from every valid probe position) */
 			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
@@ -804,24 +857,35 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments(CompressArgs A)
 {
-	compress_fragment_body<false, false>(A);
+	compress_fragment_body<false, false, false>(A);
 }
 
 /* hash table in global memory (more fragments per CU when the table would fill the LDS) */
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab(CompressArgs A)
 {
-	compress_fragment_body<false, true>(A);
+	compress_fragment_body<false, true, false>(A);
+}
+
+/* hash table in global memory and the window read in place (no LDS copy of the input) */
+extern "C" __global__ void __launch_bounds__(128, 6) snappy_compress_fragments_gwin(CompressArgs A)
+{
+	compress_fragment_body<false, true, true>(A);
 }
 
 /* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_prof(CompressArgs A)
 {
-	compress_fragment_body<true, false>(A);
+	compress_fragment_body<true, false, false>(A);
 }
 
 extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab_prof(CompressArgs A)
 {
-	compress_fragment_body<true, true>(A);
+	compress_fragment_body<true, true, false>(A);
+}
+
+extern "C" __global__ void __launch_bounds__(128, 6) snappy_compress_fragments_gwin_prof(CompressArgs A)
+{
+	compress_fragment_body<true, true, true>(A);
 }
 
 /* ==========================================================================================
@@ -1104,27 +1168,36 @@ constexpr uint32_t kMaxGlobalTables = 16384; /* fragments per launch in global-t
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 
-size_t compress_lds_bytes(uint32_t win_bytes, int p, bool gtab, uint32_t *s_entries)
+/* placement: 0 = table and window in LDS, 1 = table in global memory, 2 = table and window in
+ * global memory */
+size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries)
 {
-	const uint32_t s_cap = gtab ? 512u : 1024u;
+	const uint32_t s_cap = placement == 1 ? 512u : 1024u;
 	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
-	return (size_t)win_bytes + (gtab ? 0 : ((size_t)1 << p)) + (size_t)*s_entries * 4 + kRingBytes + kStageBytes;
+	return (size_t)(placement == 2 ? 0 : win_bytes) + (placement ? 0 : ((size_t)1 << p)) + (size_t)*s_entries * 4 +
+	       kRingBytes + kStageBytes;
 }
 
-/* Where the hash table lives.  In LDS it is one round trip closer, but with a 32 KiB window it
- * leaves room for only 1-3 fragments per CU; in global memory (L2 / Infinity Cache resident)
- * four fragments fit.  Measured on MI355X (tools/mode_matrix.py): global wins whenever the LDS
- * form fits fewer than four workgroups per CU, LDS wins for 4 KiB pages (7 per CU).
- * CSNAPPY_HIP_TABLE=lds|global overrides the choice (experiments). */
-bool use_global_table(uint32_t win_bytes, int p)
+/* Where the hash table and the window live.  In LDS they are one round trip closer, but a
+ * 32 KiB window plus a 2^p-byte table leave room for only 1-3 fragments per CU, and the kernel
+ * is bound by the latency of ONE wave's dependent chain per fragment -- so fragments in flight
+ * per CU is what buys throughput.  With both in global memory (L2 / Infinity Cache resident)
+ * a fragment needs ~9 KiB of LDS and 12 fit.  Measured on MI355X (tools/mode_matrix.py, G_text,
+ * 64 KiB blocks, p=16): LDS 9 GiB/s, table in global 21 GiB/s, table+window in global 30 GiB/s;
+ * 4 KiB pages at p=13 (7 per CU in LDS) are fastest in LDS.  So: LDS when at least four
+ * fragments fit a CU that way, otherwise global.  CSNAPPY_HIP_TABLE=lds|global|gwin overrides the
+ * choice (experiments). */
+int choose_placement(uint32_t win_bytes, int p)
 {
 	const char *e = getenv("CSNAPPY_HIP_TABLE");
 	if (e && !strcmp(e, "global"))
-		return true;
+		return 1;
+	if (e && !strcmp(e, "gwin"))
+		return 2;
 	if (e && !strcmp(e, "lds"))
-		return false;
+		return 0;
 	uint32_t se;
-	return kLdsPerCu / compress_lds_bytes(win_bytes, p, false, &se) < 4;
+	return kLdsPerCu / compress_lds_bytes(win_bytes, p, 0, &se) < 4 ? 2 : 0;
 }
 
 uint32_t frags_per_block(uint32_t max_in_len)
@@ -1221,8 +1294,15 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.nblocks = nblocks;
 	A.fpb = fpb;
 	A.win_bytes = ((max_in_len < kFragment ? max_in_len : kFragment) + 16 + 16 + 63) & ~63u;
-	const bool gtab = use_global_table(A.win_bytes, p);
-	const size_t lds = compress_lds_bytes(A.win_bytes, p, gtab, &A.s_entries);
+	const int placement = choose_placement(A.win_bytes, p);
+	const bool gtab = placement != 0;
+	size_t lds = compress_lds_bytes(A.win_bytes, p, placement, &A.s_entries);
+	if (const char *w = getenv("CSNAPPY_HIP_WGS_PER_CU")) {
+		/* experiments: cap the workgroups per CU by padding the LDS request */
+		const int k = atoi(w);
+		if (k > 0 && kLdsPerCu / k > lds)
+			lds = (kLdsPerCu / k) & ~(size_t)255;
+	}
 	A.p = p;
 	A.mode = mode;
 	A.prof = g_prof_buf;
@@ -1235,10 +1315,15 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	}
 	A.id_base = 0;
 
-	const void *kfn = gtab ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_compress_fragments_gtab_prof)
-					     : reinterpret_cast<const void *>(snappy_compress_fragments_gtab))
-			       : (g_prof_buf ? reinterpret_cast<const void *>(snappy_compress_fragments_prof)
-					     : reinterpret_cast<const void *>(snappy_compress_fragments));
+	const void *kfns[3][2] = {
+		{ reinterpret_cast<const void *>(snappy_compress_fragments),
+		  reinterpret_cast<const void *>(snappy_compress_fragments_prof) },
+		{ reinterpret_cast<const void *>(snappy_compress_fragments_gtab),
+		  reinterpret_cast<const void *>(snappy_compress_fragments_gtab_prof) },
+		{ reinterpret_cast<const void *>(snappy_compress_fragments_gwin),
+		  reinterpret_cast<const void *>(snappy_compress_fragments_gwin_prof) },
+	};
+	const void *kfn = kfns[placement][g_prof_buf ? 1 : 0];
 	if (!hip_ok(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
 		    "hipFuncSetAttribute"))
 		return CSNAPPY_HIP_E_RUNTIME;
