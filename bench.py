@@ -42,12 +42,12 @@ def log(*a):
 
 
 def load_measured_traffic(workload, p):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, produced by tools/profile_traffic.py), or None."""
+    """HBM bytes per batch call of the dominant kernel from committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools/profile_commit.py), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        return t.get(f"{workload}_p{p}", {}).get("snappy_compress_fragments_bytes_per_launch")
+        return t.get(f"{workload}_p{p}", {}).get("snappy_compress_fragments_bytes_per_batch")
     except (OSError, ValueError):
         return None
 

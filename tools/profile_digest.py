@@ -22,7 +22,12 @@ def rows(pattern):
             yield from csv.DictReader(f)
 
 
-summary = {"bench_args": args, "kernels": {}, "pmc": {}}
+summary = {"bench_args": args, "kernels": {}, "pmc": {}, "per_batch": {}}
+
+
+def family(name):
+    """compress runs as one or more chunk launches of one of its instantiations per batch call"""
+    return "snappy_compress_fragments" if name.startswith("snappy_compress_fragments") else name
 for r in rows("stats/**/*kernel_stats.csv"):
     name = r.get("Name", "")
     if "snappy" in name or "workload" in name:
@@ -52,4 +57,22 @@ try:
     summary["bench_line"] = json.loads(open(os.path.join(out, "bench_stats.json")).read().strip().splitlines()[-1])
 except Exception as e:  # noqa
     summary["bench_line"] = f"unreadable: {e!r}"
+
+# per BATCH CALL figures (what bench.py's HIP events measure): a batch = steps + warmup calls
+try:
+    batches = summary["bench_line"]["steps"] + summary["bench_line"]["warmup"]
+    for name, k in summary["kernels"].items():
+        f = summary["per_batch"].setdefault(family(name), {"ms": 0.0, "launches_per_batch": 0.0})
+        f["ms"] += k["total_ns"] / batches / 1e6
+        f["launches_per_batch"] += k["calls"] / batches
+    for name, v in summary["pmc"].items():
+        f = summary["per_batch"].setdefault(family(name), {})
+        if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+            fetch = v["FETCH_SIZE_KiB_per_launch"] * v["launches_FETCH_SIZE"] / batches * 1024
+            write = v["WRITE_SIZE_KiB_per_launch"] * v["launches_WRITE_SIZE"] / batches * 1024
+            f["fetch_bytes_raw"] = f.get("fetch_bytes_raw", 0) + int(fetch)
+            f["write_bytes_raw"] = f.get("write_bytes_raw", 0) + int(write)
+            f["hbm_bytes_corrected"] = f.get("hbm_bytes_corrected", 0) + int(2 * fetch + write)
+except Exception as e:  # noqa
+    summary["per_batch"] = f"unavailable: {e!r}"
 print(json.dumps(summary, indent=1))
