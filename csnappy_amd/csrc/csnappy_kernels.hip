@@ -938,7 +938,62 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stitch_blocks(CompressA
 
 /* ==========================================================================================
  * DECOMPRESS: one wave per block
+ *
+ * Per iteration the 64 lanes look at the 64 input bytes at ip..ip+63, each decoding its byte as
+ * if it were a tag.  The true tag chain is walked on the scalar unit, a wave prefix sum gives
+ * each element its output offset, the reference's checks are evaluated per element in its
+ * order, and the elements in front of the first failing one are executed in three passes:
+ *   1. literals, one lane per element (they depend on the input only),
+ *   2. copies whose source lies entirely in front of this batch's output, one lane per element,
+ *   3. the remaining copies (source inside the batch, or overlapping themselves) one after the
+ *      other with the whole wave, dst[j] = dst[j mod offset - offset]  (:188-206 semantics).
  * ======================================================================================== */
+
+/* inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS) */
+template <int CTRL, int ROW_MASK> DEVINL uint32_t dpp_add(uint32_t x)
+{
+	return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+
+DEVINL uint32_t wave_incl_scan_dpp(uint32_t x)
+{
+	x = dpp_add<0x111, 0xf>(x); /* row_shr:1 */
+	x = dpp_add<0x112, 0xf>(x); /* row_shr:2 */
+	x = dpp_add<0x114, 0xf>(x); /* row_shr:4 */
+	x = dpp_add<0x118, 0xf>(x); /* row_shr:8 */
+	x = dpp_add<0x142, 0xa>(x); /* row_bcast:15 -> rows 1 and 3 */
+	x = dpp_add<0x143, 0xc>(x); /* row_bcast:31 -> rows 2 and 3 */
+	return x;
+}
+
+/* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment */
+DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
+{
+	uint32_t k = 0;
+	while (__ballot(active && k + 8 <= len)) {
+		if (active && k + 8 <= len) {
+			uint64_t v;
+			__builtin_memcpy(&v, s + k, 8);
+			__builtin_memcpy(d + k, &v, 8);
+			k += 8;
+		}
+	}
+	if (active && len - k >= 4) {
+		uint32_t v;
+		__builtin_memcpy(&v, s + k, 4);
+		__builtin_memcpy(d + k, &v, 4);
+		k += 4;
+	}
+	if (active && len - k >= 2) {
+		uint16_t v;
+		__builtin_memcpy(&v, s + k, 2);
+		__builtin_memcpy(d + k, &v, 2);
+		k += 2;
+	}
+	if (active && len - k >= 1)
+		d[k] = s[k];
+}
+
 extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(DecompressArgs A)
 {
 	const uint32_t lane = threadIdx.x;
@@ -978,12 +1033,19 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		/* ---- every lane decodes the byte at ip+lane as if it were a tag ---- */
 		const uint64_t at = ip + lane;
 		uint32_t b0 = 0, tr = 0;
-		if (at < n)
-			b0 = src[at];
+		if (at + 8 <= n) {
+			uint64_t v;
+			__builtin_memcpy(&v, src + at, 8);
+			b0 = (uint32_t)v & 0xff;
+			tr = (uint32_t)(v >> 8);
+		} else {
+			if (at < n)
+				b0 = src[at];
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-			if (at + 1 + k < n)
-				tr |= (uint32_t)src[at + 1 + k] << (8 * k);
+			for (int k = 0; k < 4; ++k)
+				if (at + 1 + k < n)
+					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
+		}
 		const uint32_t kind = b0 & 3;
 		uint32_t l, extra, off = 0;
 		if (kind == 0) {
@@ -1001,14 +1063,18 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			off = kind == 2 ? (tr & 0xffff) : tr;
 		}
 		const uint32_t hsz = 1 + extra;
+		/* bytes this element takes in the input (a literal length that would wrap 32 bits is
+		 * negative as int32 and fails below whatever the walk does after it) */
+		const uint32_t esz = kind == 0 ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
 
 		/* ---- walk the real tag chain on the scalar unit ---- */
 		uint64_t tmask = 0;
 		uint64_t cur = 0;
-		while (cur < 64 && ip + cur < n) {
+		const uint64_t room = n - ip; /* > 0 */
+		while (cur < 64 && cur < room) {
 			const uint32_t cl = (uint32_t)cur;
 			tmask |= 1ull << cl;
-			cur += rdlane(hsz, cl) + (rdlane(kind, cl) == 0 ? (uint64_t)rdlane(l, cl) : 0ull);
+			cur += rdlane(esz, cl);
 		}
 		const bool istag = (tmask >> lane) & 1;
 
@@ -1019,8 +1085,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const bool lit_neg = kind == 0 && (int32_t)l < 0;
 		const bool inbad = trunc || lit_short || lit_neg;
 		const uint32_t eff = (istag && !inbad) ? l : 0;
-		uint32_t total;
-		const uint32_t excl = wave_excl_scan(eff, lane, &total);
+		const uint32_t excl = wave_incl_scan_dpp(eff) - eff;
 		const uint64_t pb = op + excl; /* bytes produced before this element */
 		int32_t err = 0;
 		if (istag) {
@@ -1039,31 +1104,40 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		}
 		const uint64_t emask = __ballot(err != 0);
 		const uint32_t fe = emask ? first_lane(emask) : 64;
+		const uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask; /* elements to execute */
+		const bool exec_me = (run >> lane) & 1;
 
-		/* ---- execute the elements before the first failing one, in order ---- */
-		uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask;
-		uint64_t done_bytes = 0;
-		for (; run; run &= run - 1) {
-			const uint32_t t = first_lane(run);
-			const uint32_t k = rdlane(kind, t), L = rdlane(l, t);
-			const uint64_t PB = op + rdlane(excl, t);
-			if (k == 0) {
-				/* SAW__Append / SAW__AppendFastPath, csnappy_decompress.c:264-293 */
-				const uint8_t *ps = src + ip + t + rdlane(hsz, t);
-				for (uint32_t j = lane; j < L; j += 64)
-					dst[PB + j] = ps[j];
-			} else {
-				/* SAW__AppendFromSelf, :295-317; dst[i] = dst[i - offset] in order
-				 * (:200-206) == replicate the `offset`-byte pattern that precedes PB */
-				const uint32_t OFF = rdlane(off, t);
-				if (lane < L) {
-					const uint32_t j = lane < OFF ? lane : lane % OFF;
-					dst[PB + lane] = dst[PB - OFF + j];
-				}
-			}
-			done_bytes = (uint64_t)rdlane(excl, t) + L;
+		/* ---- pass 1: literals (SAW__Append / SAW__AppendFastPath, :264-293) ---- */
+		const uint8_t *lsrc = src + at + hsz;
+		uint8_t *edst = dst + pb;
+		const bool lit = exec_me && kind == 0;
+		copy_exact(edst, lsrc, l, lit && l <= 64);
+		for (uint64_t big = __ballot(lit && l > 64); big; big &= big - 1) {
+			const uint32_t t = first_lane(big);
+			const uint32_t L = rdlane(l, t);
+			const uint8_t *ps = src + ip + t + rdlane(hsz, t);
+			uint8_t *pd = dst + op + rdlane(excl, t);
+			for (uint32_t j = lane; j < L; j += 64)
+				pd[j] = ps[j];
 		}
-		op += done_bytes;
+		/* ---- pass 2: copies that read only what earlier batches produced ---- */
+		const bool cpy = exec_me && kind != 0;
+		const bool indep = cpy && off >= excl + l;
+		copy_exact(edst, edst - off, l, indep);
+		/* ---- pass 3: the other copies, in order (SAW__AppendFromSelf, :295-317) ---- */
+		for (uint64_t dep = __ballot(cpy && !indep); dep; dep &= dep - 1) {
+			const uint32_t t = first_lane(dep);
+			const uint32_t L = rdlane(l, t), OFF = rdlane(off, t);
+			uint8_t *pd = dst + op + rdlane(excl, t);
+			if (lane < L) {
+				const uint32_t j = lane < OFF ? lane : lane % OFF;
+				pd[lane] = pd[(int64_t)j - (int64_t)OFF];
+			}
+		}
+		if (run) {
+			const uint32_t t = 63u - (uint32_t)__builtin_clzll(run); /* last executed element */
+			op += (uint64_t)rdlane(excl, t) + rdlane(l, t);
+		}
 		if (fe < 64) {
 			status = (int32_t)rdlane((uint32_t)err, fe);
 			break;
