@@ -630,16 +630,35 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t key = h & smask;
 			if (valid_c)
 				atomicMin(&S[key], (epoch << 6) | lane);
-			const uint32_t cand = tab[h];
-			wave_lds_fence();
-			const uint32_t first_same = S[key] & 63u; /* lowest valid lane with my slot key */
+			uint32_t cand = 0, first_same;
+			int c1, v, ulim;
+			if (GTAB) {
+				/* the table (and window) gathers go to L2/HBM: resolve the slot sharing first
+				 * (LDS only) so that lanes behind the cut do not gather at all */
+				wave_lds_fence();
+				first_same = S[key] & 63u; /* lowest valid lane with my slot key */
+				const uint64_t cmask = __ballot(valid_c && first_same < lane);
+				const uint64_t imask = ~__ballot(valid_c);
+				c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
+				v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
+				ulim = min(c1, v);
+				if ((int)lane < ulim)
+					cand = tab[h];
+			} else {
+				cand = tab[h];
+				wave_lds_fence();
+				first_same = S[key] & 63u;
+			}
+			cb[0] = cb[1] = cb[2] = cb[3] = 0;
 			if (GWIN) {
-				uint4 v; /* cand < pos, so these 16 bytes are inside the fragment too */
-				__builtin_memcpy(&v, win8 + wbase + cand, 16);
-				cb[0] = v.x;
-				cb[1] = v.y;
-				cb[2] = v.z;
-				cb[3] = v.w;
+				if ((int)lane < ulim) {
+					uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
+					__builtin_memcpy(&w4, win8 + wbase + cand, 16);
+					cb[0] = w4.x;
+					cb[1] = w4.y;
+					cb[2] = w4.z;
+					cb[3] = w4.w;
+				}
 			} else {
 				lds_rd128(win32, wbase + cand, cb);
 			}
@@ -649,11 +668,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
 			const uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
 					    : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
-			const uint64_t cmask = __ballot(valid_c && first_same < lane);
-			const uint64_t imask = ~__ballot(valid_c);
-			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
-			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
-			const int ulim = min(c1, v);
+			if (!GTAB) {
+				const uint64_t cmask = __ballot(valid_c && first_same < lane);
+				const uint64_t imask = ~__ballot(valid_c);
+				c1 = cmask ? (int)first_lane(cmask) : 64;
+				v = imask ? (int)first_lane(imask) : 64;
+				ulim = min(c1, v);
+			}
 			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
 			epoch--;
 			if (PROF) {
