@@ -65,32 +65,43 @@ def cpu_baseline(kind, seed, block, p, mode, nblocks_avail, target_s, urls=None)
         rep = np.frombuffer(urls, dtype=np.uint8)
         return np.resize(rep, nb * block)
 
+    bufs = {}
+
     def run(nb, threads):
-        host = sample(nb)
-        b = api.Batch([block] * nb, device=None)
+        # buffers are allocated and touched once, outside the timed calls
+        if bufs.get("nb") != nb:
+            b = api.Batch([block] * nb, device=None)
+            bufs.update(nb=nb, host=sample(nb), b=b, comp=np.ones(b.out_bytes + 64, dtype=np.uint8),
+                        back=np.ones(nb * block + 64, dtype=np.uint8), cap=np.full(nb, block, dtype=np.uint32))
+        host, b = bufs["host"], bufs["b"]
         t0 = time.perf_counter()
         out, out_len = oracle.batch_compress(codec, host, b.in_off, b.in_len, b.out_off, b.out_bytes,
-                                             p, mode, threads=threads)
+                                             p, mode, threads=threads, out=bufs["comp"])
         t1 = time.perf_counter()
-        cap = np.full(nb, block, dtype=np.uint32)
-        back, status, _ = oracle.batch_decompress(codec, out, b.out_off, out_len, b.in_off, cap,
-                                                  nb * block, mode, threads=threads)
+        back, status, _ = oracle.batch_decompress(codec, bufs["comp"], b.out_off, out_len, b.in_off, bufs["cap"],
+                                                  nb * block, mode, threads=threads, out=bufs["back"])
         t2 = time.perf_counter()
-        assert (status == 0).all() and np.array_equal(back, host)
+        assert (status == 0).all() and np.array_equal(back[:nb * block], host)
         return t1 - t0, t2 - t1
 
     probe = max(cores * 4, (8 << 20) // block)
     tc, td = run(probe, cores)
     per_block = (tc + td) / probe
     nb = int(min(nblocks_avail, max(probe, target_s / per_block)))
-    nb = min(nb, (6 << 30) // block)  # bound host memory
-    tc, td = run(nb, cores)
-    gib = nb * block / 2.0 ** 30
+    nb = min(nb, (4 << 30) // block)  # bound host memory
+    # repeat the sample until ~target_s of CPU work has been timed
+    reps = int(max(1, min(64, target_s / max(per_block * nb, 1e-6))))
+    tc = td = 0.0
+    for _ in range(reps):
+        a, b_ = run(nb, cores)
+        tc += a
+        td += b_
+    gib = nb * block * reps / 2.0 ** 30
     return {
         "value": round(gib / (tc + td), 4), "unit": "GiB/s", "cores": cores, "kind": codec.kind,
-        "sample": f"first {nb} blocks x {block} B of the same workload ({gib:.3f} GiB), "
-                  f"compress {tc:.2f} s + decompress {td:.2f} s on {cores} threads "
-                  "(one block range per thread)",
+        "sample": f"first {nb} blocks x {block} B of the same workload, {reps} repetition(s) "
+                  f"({gib:.3f} GiB in total): compress {tc:.2f} s + decompress {td:.2f} s on {cores} "
+                  "threads (one block range per thread)",
         "compress_gibs": round(gib / tc, 4), "decompress_gibs": round(gib / td, 4),
     }
 

@@ -128,16 +128,28 @@ template <bool G> DEVINL uint64_t win_rd64(const uint32_t *w, uint32_t byte)
 	return lds_rd64(w, byte);
 }
 
+/* inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS) */
+template <int CTRL, int ROW_MASK> DEVINL uint32_t dpp_add(uint32_t x)
+{
+	return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+
+DEVINL uint32_t wave_incl_scan_dpp(uint32_t x)
+{
+	x = dpp_add<0x111, 0xf>(x); /* row_shr:1 */
+	x = dpp_add<0x112, 0xf>(x); /* row_shr:2 */
+	x = dpp_add<0x114, 0xf>(x); /* row_shr:4 */
+	x = dpp_add<0x118, 0xf>(x); /* row_shr:8 */
+	x = dpp_add<0x142, 0xa>(x); /* row_bcast:15 -> rows 1 and 3 */
+	x = dpp_add<0x143, 0xc>(x); /* row_bcast:31 -> rows 2 and 3 */
+	return x;
+}
+
 /* exclusive prefix sum across the 64 lanes; *total receives the wave sum */
 DEVINL uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t *total)
 {
-	uint32_t x = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
-		if (lane >= (uint32_t)d)
-			x += y;
-	}
+	(void)lane;
+	const uint32_t x = wave_incl_scan_dpp(v);
 	*total = rdlane(x, 63);
 	return x - v;
 }
@@ -969,23 +981,6 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stitch_blocks(CompressA
  *   3. the remaining copies (source inside the batch, or overlapping themselves) one after the
  *      other with the whole wave, dst[j] = dst[j mod offset - offset]  (:188-206 semantics).
  * ======================================================================================== */
-
-/* inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS) */
-template <int CTRL, int ROW_MASK> DEVINL uint32_t dpp_add(uint32_t x)
-{
-	return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
-}
-
-DEVINL uint32_t wave_incl_scan_dpp(uint32_t x)
-{
-	x = dpp_add<0x111, 0xf>(x); /* row_shr:1 */
-	x = dpp_add<0x112, 0xf>(x); /* row_shr:2 */
-	x = dpp_add<0x114, 0xf>(x); /* row_shr:4 */
-	x = dpp_add<0x118, 0xf>(x); /* row_shr:8 */
-	x = dpp_add<0x142, 0xa>(x); /* row_bcast:15 -> rows 1 and 3 */
-	x = dpp_add<0x143, 0xc>(x); /* row_bcast:31 -> rows 2 and 3 */
-	return x;
-}
 
 /* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment */
 DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)

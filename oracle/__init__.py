@@ -224,14 +224,16 @@ def best():
 # Batched drivers over host numpy arrays (same descriptor layout as the HIP batch API): used to
 # check whole batches and to time the CPU baseline on `threads` host cores.
 # ---------------------------------------------------------------------------------------------
-def batch_compress(codec, data, in_off, in_len, out_off, out_bytes, p, mode, threads=1):
+def batch_compress(codec, data, in_off, in_len, out_off, out_bytes, p, mode, threads=1, out=None):
+    """`out`: optional preallocated (and already touched) uint8 buffer of out_bytes + 64."""
     port = Port()
     cfn, ffn, _, _ = codec._fnptrs()
     data = _as_u8(data)
     in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
     in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
     out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
-    out = np.zeros(out_bytes + 64, dtype=np.uint8)
+    if out is None:
+        out = np.zeros(out_bytes + 64, dtype=np.uint8)
     out_len = np.zeros(len(in_len), dtype=np.uint32)
     nb = len(in_len)
 
@@ -243,15 +245,17 @@ def batch_compress(codec, data, in_off, in_len, out_off, out_bytes, p, mode, thr
     return out[:out_bytes], out_len
 
 
-def batch_decompress(codec, data, in_off, in_len, out_off, out_cap, out_bytes, mode, threads=1):
+def batch_decompress(codec, data, in_off, in_len, out_off, out_cap, out_bytes, mode, threads=1, out=None):
+    """`data` must be readable 16 bytes past its last block when `out` is given (no copy is made)."""
     port = Port()
     _, _, dfn, nfn = codec._fnptrs()
-    data = np.concatenate([_as_u8(data), np.zeros(16, np.uint8)])
+    data = np.concatenate([_as_u8(data), np.zeros(16, np.uint8)]) if out is None else _as_u8(data)
     in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
     in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
     out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
     out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
-    out = np.zeros(out_bytes + 64, dtype=np.uint8)
+    if out is None:
+        out = np.zeros(out_bytes + 64, dtype=np.uint8)
     nb = len(in_len)
     status = np.zeros(nb, dtype=np.int32)
     produced = np.zeros(nb, dtype=np.uint32)
