@@ -405,3 +405,25 @@ def test_cl_tester_round_trip_and_selftests(torch, urls, golden_dir, tmp_path):
     # -S c: the compressor does not bounds-check its output; the reference expects the fault
     sc = _cli(["-S", "c"])
     assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)
+
+
+@pytest.mark.parametrize("placement", ["lds", "global", "gwin"])
+def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
+    """The compress kernel has three instantiations (hash table / window in LDS or in global
+    memory); the library picks one by LDS occupancy.  Force each and check the same bytes."""
+    monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+    xs = list(_ragged_cases(900, 40))
+    host = np.concatenate(xs)
+    lens = [len(x) for x in xs]
+    for p, mode in ((16, api.STREAM), (13, api.STREAM), (15, api.FRAGMENT)):
+        if mode == api.FRAGMENT:
+            ys = [x[:32768] for x in xs]
+            h2, l2 = np.concatenate(ys), [len(y) for y in ys]
+        else:
+            h2, l2 = host, lens
+        blocks, _, _ = gpu_compress(torch, h2, l2, p, mode)
+        assert blocks == oracle_blocks(chk, h2, l2, p, mode), (placement, p, mode)
+    g = GOLD["workloads"]["G_text_64k_p16"]
+    d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
+    blocks, _, _ = gpu_compress(torch, d_in.cpu().numpy(), [g["block"]] * g["nblocks"], g["p"], g["mode"])
+    assert sha(b"".join(blocks)) == g["sha256"]
