@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0, help="uncompressed GiB per GPU")
     ap.add_argument("--p", type=int, default=None, help="table power (default per workload)")
     ap.add_argument("--block", type=int, default=None, help="block bytes (default per workload)")
+    ap.add_argument("--chunk-gib", type=float, default=8.0,
+                    help="blocks are processed in chunks of this many GiB (bounds the output/workspace "
+                         "memory of very large batches; the whole input stays resident)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true",
@@ -154,19 +157,33 @@ def main():
         idx = (torch.arange(nb * block, device="cuda", dtype=torch.int64) + first * block) % len(urls)
         d_in = rep[idx]
         del idx
-    b = api.Batch([block] * nb)
+    # the batch is processed in chunks of <= chunk_gib (one chunk for the default 1 GiB workload)
+    cb = max(1, min(nb, int(args.chunk_gib * 2 ** 30) // block))  # blocks per chunk
+    chunks = [(lo, min(cb, nb - lo)) for lo in range(0, nb, cb)]
+    b = api.Batch([block] * cb)
     d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
-    d_back = torch.zeros(nb * block, dtype=torch.uint8, device="cuda")
-    cap = torch.full((nb,), block, dtype=torch.int32, device="cuda")
-    status = torch.full((nb,), -99, dtype=torch.int32, device="cuda")
-    produced = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_back = torch.zeros(cb * block, dtype=torch.uint8, device="cuda")
+    cap = torch.full((cb,), block, dtype=torch.int32, device="cuda")
+    status = torch.full((cb,), -99, dtype=torch.int32, device="cuda")
+    produced = torch.zeros(cb, dtype=torch.int32, device="cuda")
+    comp_total = torch.zeros(1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
 
-    def step():
-        api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len,
-                           p, mode, b.d_ws)
-        api.decompress_batch(d_out, b.d_out_off, b.d_out_len, d_back, b.d_in_off, cap, status, produced,
-                             mode)
+    def run_chunk(lo, cnt, check=False):
+        src = d_in[lo * block:(lo + cnt) * block]
+        api.compress_batch(src, b.d_in_off[:cnt], b.d_in_len[:cnt], b.max_in_len, d_out, b.d_out_off[:cnt],
+                           b.d_out_len[:cnt], p, mode, b.d_ws)
+        api.decompress_batch(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt], d_back, b.d_in_off[:cnt], cap[:cnt],
+                             status[:cnt], produced[:cnt], mode)
+        if check:  # outside the timed region only
+            torch.cuda.synchronize()
+            assert (status[:cnt] == 0).all().item(), "decompress reported an error"
+            assert torch.equal(d_back[:cnt * block], src), "round trip differs from the input"
+            comp_total.add_(b.d_out_len[:cnt].to(torch.int64).sum())
+
+    def step(check=False):
+        for lo, cnt in chunks:
+            run_chunk(lo, cnt, check)
 
     def barrier():
         torch.cuda.synchronize()
@@ -174,16 +191,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # results are checked outside the timed region: every block of every chunk round-trips
+    step(check=True)
+    comp_bytes = int(comp_total.item())
+    for _ in range(max(0, args.warmup - 1)):
         step()
     torch.cuda.synchronize()
-    if args.warmup == 0:
-        step()
-        torch.cuda.synchronize()
-    # results are checked outside the timed region: every block round-trips
-    assert (status == 0).all().item(), "decompress reported an error"
-    assert torch.equal(d_back, d_in), "round trip differs from the input"
-    comp_bytes = int(b.d_out_len.to(torch.int64).sum().item())
 
     # ---- timed region: exactly K steps ----------------------------------------------------------
     api.get_kernel_timing()
@@ -203,11 +216,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = t.item()
     n_bytes = nb * block
-    kernels = {k: {"avg_ms": round(ms / max(c, 1), 4), "launches": c} for k, (ms, c) in kt.items()}
+    # a "launch" below is one batch call of the C-ABI (per chunk); ms_per_step sums the chunks
+    kernels = {k: {"avg_ms": round(ms / max(c, 1), 4), "launches": c,
+                   "ms_per_step": round(ms / args.steps, 4)} for k, (ms, c) in kt.items()}
 
     gather = None
     if args.gather and dist is not None:
-        gather = shard.time_gather_compacted(d_out, b, dist, world)
+        gather = shard.time_gather_compacted(d_out, b, dist, world)  # the last chunk's output
 
     if rank != 0:
         if dist is not None:
@@ -220,14 +235,16 @@ def main():
            "snappy_stitch_blocks": comp_bytes,  # <= half of C is moved (read + write)
            "snappy_decompress_blocks": comp_bytes + n_bytes}
     dom = max(("snappy_compress_fragments", "snappy_decompress_blocks"),
-              key=lambda k: kernels[k]["avg_ms"])
-    dom_s = kernels[dom]["avg_ms"] / 1e3
+              key=lambda k: kernels[k]["ms_per_step"])
+    nch = len(chunks)
+    dom_s = kernels[dom]["ms_per_step"] / 1e3
     achieved = alg[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
-    traffic = load_measured_traffic(args.workload, p) if dom == "snappy_compress_fragments" else None
+    traffic = load_measured_traffic(args.workload, p) if (dom == "snappy_compress_fragments" and nch == 1
+                                                          and args.gib == 1.0 and args.block is None) else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
-                "traffic": traffic}
+                "algorithmic_bytes_per_launch": alg[dom] // nch, "avg_launch_ms": kernels[dom]["avg_ms"],
+                "launches_per_step": nch, "traffic": traffic}
 
     gibs = lambda ms: round(n_bytes * world / (ms / 1e3) / 2 ** 30, 3) if ms > 0 else None
     out = {
@@ -244,11 +261,12 @@ def main():
                                "compress then decompress (round trip), inputs resident in HBM",
                    "block_bytes": block, "blocks_per_gpu": nb, "table_power": p,
                    "mode": "STREAM" if mode == 0 else "FRAGMENT", "seed": hex(seed),
+                   "chunks_per_step": len(chunks),
                    "sharding": f"block ranges, {world} rank(s), no data-path collective"},
         "compressed_ratio": round(comp_bytes / n_bytes, 6),
-        "compress_gibs": gibs(kernels["snappy_compress_fragments"]["avg_ms"]
-                              + kernels["snappy_stitch_blocks"]["avg_ms"]),
-        "decompress_gibs": gibs(kernels["snappy_decompress_blocks"]["avg_ms"]),
+        "compress_gibs": gibs(kernels["snappy_compress_fragments"]["ms_per_step"]
+                              + kernels["snappy_stitch_blocks"]["ms_per_step"]),
+        "decompress_gibs": gibs(kernels["snappy_decompress_blocks"]["ms_per_step"]),
         "kernels": kernels,
         "roofline": roofline,
     }

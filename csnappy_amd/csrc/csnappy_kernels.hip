@@ -65,6 +65,7 @@ struct CompressArgs {
 	unsigned long long *prof; /* debug cycle counters (PROF instantiation only) */
 	uint16_t *gtab;   /* GTAB instantiation: one 2^p-byte hash table per workgroup of the launch */
 	uint32_t id_base; /* first fragment id of this launch (launches are chunked in GTAB mode) */
+	uint32_t width;   /* lanes that take a position per dense step (experiments; 64) */
 };
 
 struct DecompressArgs {
@@ -652,6 +653,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				const uint64_t cmask = __ballot(valid_c && first_same < lane);
 				const uint64_t imask = ~__ballot(valid_c);
 				c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
+				c1 = min(c1, (int)A.width);
 				v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
 				ulim = min(c1, v);
 				if ((int)lane < ulim)
@@ -1404,6 +1406,9 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		A.gtab = reinterpret_cast<uint16_t *>(t);
 	}
 	A.id_base = 0;
+	A.width = 64;
+	if (const char *w = getenv("CSNAPPY_HIP_STEP_WIDTH"))
+		A.width = (uint32_t)atoi(w);
 
 	const void *kfns[3][2] = {
 		{ reinterpret_cast<const void *>(snappy_compress_fragments),

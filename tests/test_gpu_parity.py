@@ -427,3 +427,42 @@ def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
     d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
     blocks, _, _ = gpu_compress(torch, d_in.cpu().numpy(), [g["block"]] * g["nblocks"], g["p"], g["mode"])
     assert sha(b"".join(blocks)) == g["sha256"]
+
+
+# -------------------------------------------------------------------------------------------------
+# next-row f2: the reference's block_compressor page container (block_compressor.c:275-394) on the
+# batched FRAGMENT path
+# -------------------------------------------------------------------------------------------------
+def test_page_container_matches_reference_format_and_round_trips(torch, chk, urls, tmp_path):
+    import struct
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "tools", "block_compressor")
+    rng = np.random.default_rng(4)
+    # text pages, two incompressible pages (stored raw), two all-zero pages, short last page
+    data = urls[:40 * 4096] + rng.integers(0, 256, 2 * 4096, dtype=np.uint8).tobytes() + bytes(2 * 4096) \
+        + urls[300000:300000 + 1671]
+    src, packed, back = tmp_path / "in.bin", tmp_path / "packed.bin", tmp_path / "back.bin"
+    src.write_bytes(data)
+    r = subprocess.run([exe, "-c", "snappy", str(src), str(packed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr
+    pages = [data[i:i + 4096] for i in range(0, len(data), 4096)]
+    lens, payload, hist = [], [], [0, 0, 0]
+    for pg in pages:
+        c = chk.compress_fragment(np.frombuffer(pg, dtype=np.uint8), 13)
+        if len(c) >= len(pg):
+            c = pg
+            hist[2] += 1
+        elif len(c) > 2048:
+            hist[1] += 1
+        else:
+            hist[0] += 1
+        lens.append(len(c))
+        payload.append(c)
+    want = struct.pack("<I", len(pages)) + struct.pack(f"<{len(pages)}I", *lens) + b"".join(payload)
+    assert packed.read_bytes() == want
+    out = r.stdout.decode()
+    assert f"#pages: {len(pages)}" in out and f"> 100%\t:{hist[2]}" in out and f"<= 50%\t:{hist[0]}" in out
+    assert hist[2] == 2
+    r = subprocess.run([exe, "-c", "snappy", "-d", str(packed), str(back)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data
