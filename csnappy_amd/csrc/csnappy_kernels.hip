@@ -1423,7 +1423,12 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		    "hipFuncSetAttribute"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	const uint32_t total = nblocks * fpb;
-	const uint32_t per_launch = gtab ? kMaxGlobalTables : total;
+	uint32_t per_launch = gtab ? kMaxGlobalTables : total;
+	if (const char *e = getenv("CSNAPPY_HIP_FRAGS_PER_LAUNCH")) {
+		const uint32_t k = (uint32_t)atoi(e); /* experiments: smaller table region */
+		if (gtab && k >= 256 && k <= kMaxGlobalTables)
+			per_launch = k;
+	}
 	Timer t(st);
 	t.start();
 	for (uint32_t base = 0; base < total; base += per_launch) {

@@ -91,3 +91,26 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".c", ".h", ".hip", ".cpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in text.replace("no CPU", ""), os.path.join(dirpath, f)
+
+
+def test_batch_api_rejects_bad_arguments_before_touching_the_device():
+    """Argument checks come first, so they can be exercised without a GPU."""
+    L = api.lib()
+    E_ARG, E_WS = -101, -103
+    ws = L.csnappy_hip_compress_workspace_size(4, 65536)
+    fake = 0x10000  # never dereferenced: every call below fails validation first
+    call = lambda nblocks, max_len, p, mode, wsp, wsb: L.csnappy_hip_compress_batch(
+        fake, fake, fake, nblocks, max_len, fake, fake, fake, p, mode, wsp, wsb, None)
+    assert call(4, 65536, 8, api.STREAM, fake, ws) == E_ARG          # p below 9
+    assert call(4, 65536, 17, api.STREAM, fake, ws) == E_ARG         # p above 16
+    assert call(4, 65536, 16, 7, fake, ws) == E_ARG                  # unknown mode
+    assert call(4, 32769, 13, api.FRAGMENT, fake, ws) == E_ARG       # a fragment is at most 32 KiB
+    assert call(4, 65536, 16, api.STREAM, fake, ws - 1) == E_WS      # workspace too small
+    assert call(4, 65536, 16, api.STREAM, fake + 8, ws) == E_WS      # workspace not 256-byte aligned
+    assert call(0, 65536, 16, api.STREAM, fake, ws) == 0             # empty batch: nothing to do
+    assert L.csnappy_hip_decompress_batch(fake, fake, fake, 4, fake, fake, fake, fake, fake, 9, None) == E_ARG
+    assert L.csnappy_hip_decompress_batch(fake, fake, fake, 0, fake, fake, fake, fake, fake, api.STREAM, None) == 0
+    assert L.csnappy_hip_workload_generate(5, 1, 0, 1, 64, fake, None) == E_ARG
+    # workspace grows with the batch and covers one staging slot per extra fragment
+    assert L.csnappy_hip_compress_workspace_size(16384, 65536) >= 16384 * 38261
+    assert L.csnappy_hip_compress_workspace_size(16384, 4096) < L.csnappy_hip_compress_workspace_size(16384, 65536)

@@ -466,3 +466,35 @@ def test_page_container_matches_reference_format_and_round_trips(torch, chk, url
     r = subprocess.run([exe, "-c", "snappy", "-d", str(packed), str(back)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == data
+
+
+def test_legacy_api_large_single_stream_and_threads(torch, chk):
+    """A 5 MiB csnappy_compress call = 160 fragments in parallel + stitch; and the legacy entry
+    points are re-entrant (reference csnappy.h has no global state): four threads at once."""
+    import threading
+    rng = np.random.default_rng(12)
+    text = api.generate_host(api.WG_TEXT, 99, 0, 40, 65536)
+    big = np.concatenate([text, rng.integers(0, 256, 1 << 20, dtype=np.uint8), np.zeros(1 << 20, np.uint8),
+                          api.generate_host(api.WG_LOW, 5, 0, 8, 65536)])[:5 * (1 << 20) + 12345]
+    for p in (16, 15):
+        got = api.compress(big, p)
+        assert got == chk.compress(big, p)
+        assert api.decompress(got, len(big)) == (0, big.tobytes())
+    inputs = [api.generate_host(api.WG_TEXT, 1000 + i, 0, 3, 65536)[:150000 + 1000 * i] for i in range(4)]
+    want = [chk.compress(x, 16) for x in inputs]
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                c = api.compress(inputs[i], 16)
+                rc, back = api.decompress(c, len(inputs[i]))
+                assert rc == 0 and back == inputs[i].tobytes()
+            got[i] = c
+        except Exception as e:  # noqa
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert got == want
