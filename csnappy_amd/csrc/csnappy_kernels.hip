@@ -59,7 +59,8 @@ struct CompressArgs {
 	uint32_t nblocks;
 	uint32_t fpb;       /* fragments per block (upper bound) */
 	uint32_t win_bytes; /* LDS bytes reserved for the window */
-	uint32_t s_entries; /* conflict-scratch entries (power of two) */
+	uint32_t s_entries; /* conflict-scratch entries per filter (power of two) */
+	uint32_t s_shift;   /* second filter's key = (h >> s_shift) & (s_entries - 1); 0 = one filter only */
 	int p;
 	int mode;
 	unsigned long long *prof; /* debug cycle counters (PROF instantiation only) */
@@ -293,7 +294,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	uint16_t *tab = GTAB ? A.gtab + ((uint64_t)blockIdx.x << (A.p - 1))
 			     : reinterpret_cast<uint16_t *>(smem + wlds);
 	uint32_t *S = reinterpret_cast<uint32_t *>(smem + wlds + (GTAB ? 0u : (1u << A.p)));
-	uint32_t *ring = S + A.s_entries;       /* [2][64] records {lit_start, base, cand, copy_len} */
+	uint32_t *S2 = S + A.s_entries; /* second filter (present iff s_shift != 0) */
+	uint32_t *ring = S + (A.s_shift ? 2 : 1) * A.s_entries; /* [2][64] records {lit_start, base, cand, copy_len} */
 	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
 	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
 	const uint32_t smask = A.s_entries - 1;
@@ -312,7 +314,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		for (uint32_t k = tid; k < ((1u << ws) >> 4); k += 128)
 			t4[k] = make_uint4(0, 0, 0, 0);
 		uint4 *s4 = reinterpret_cast<uint4 *>(S);
-		for (uint32_t k = tid; k < (A.s_entries >> 2); k += 128)
+		for (uint32_t k = tid; k < (((A.s_shift ? 2 : 1) * A.s_entries) >> 2); k += 128)
 			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 	}
 	__syncthreads();
@@ -640,9 +642,17 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t me2 = __builtin_amdgcn_alignbyte(raw[3], raw[2], rsh);
 			const uint32_t me3 = __builtin_amdgcn_alignbyte(raw[4], raw[3], rsh);
 			const uint32_t h = (me0 * kHashMul) >> shift;
+			/* slot sharing inside a step is detected with one or two small filters keyed by
+			 * different bits of the hash: a lane is cut only if BOTH report an earlier lane
+			 * (two lanes with the same slot collide in both; a false alarm needs two
+			 * independent key collisions) */
 			const uint32_t key = h & smask;
-			if (valid_c)
+			const uint32_t key2 = (h >> A.s_shift) & smask;
+			if (valid_c) {
 				atomicMin(&S[key], (epoch << 6) | lane);
+				if (A.s_shift)
+					atomicMin(&S2[key2], (epoch << 6) | lane);
+			}
 			uint32_t cand = 0, first_same;
 			int c1, v, ulim;
 			if (GTAB) {
@@ -650,6 +660,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				 * (LDS only) so that lanes behind the cut do not gather at all */
 				wave_lds_fence();
 				first_same = S[key] & 63u; /* lowest valid lane with my slot key */
+				if (A.s_shift)
+					first_same = max(first_same, S2[key2] & 63u);
 				const uint64_t cmask = __ballot(valid_c && first_same < lane);
 				const uint64_t imask = ~__ballot(valid_c);
 				c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
@@ -662,6 +674,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				cand = tab[h];
 				wave_lds_fence();
 				first_same = S[key] & 63u;
+				if (A.s_shift)
+					first_same = max(first_same, S2[key2] & 63u);
 			}
 			cb[0] = cb[1] = cb[2] = cb[3] = 0;
 			if (GWIN) {
@@ -1262,11 +1276,22 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
 
 /* placement: 0 = table and window in LDS, 1 = table in global memory, 2 = table and window in
  * global memory */
-size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries)
+size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries, uint32_t *s_shift)
 {
-	const uint32_t s_cap = placement == 1 ? 512u : 1024u;
+	uint32_t s_cap = placement == 1 ? 512u : 1024u;
+	if (const char *e = getenv("CSNAPPY_HIP_S_ENTRIES")) /* experiments */
+		s_cap = (uint32_t)atoi(e);
 	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
-	return (size_t)(placement == 2 ? 0 : win_bytes) + (placement ? 0 : ((size_t)1 << p)) + (size_t)*s_entries * 4 +
+	/* a second filter on the upper hash bits when one filter cannot be exact (global placements:
+	 * there every lane kept in front of the cut is two cache-line gathers, and LDS is plentiful) */
+	uint32_t bits = 0;
+	while ((1u << bits) < *s_entries)
+		++bits;
+	*s_shift = (placement != 0 && (1u << (p - 1)) > *s_entries) ? (uint32_t)(p - 1) - bits : 0;
+	if (getenv("CSNAPPY_HIP_ONE_FILTER"))
+		*s_shift = 0;
+	return (size_t)(placement == 2 ? 0 : win_bytes) + (placement ? 0 : ((size_t)1 << p)) +
+	       (size_t)*s_entries * 4 * (*s_shift ? 2 : 1) +
 	       kRingBytes + kStageBytes;
 }
 
@@ -1288,8 +1313,8 @@ int choose_placement(uint32_t win_bytes, int p)
 		return 2;
 	if (e && !strcmp(e, "lds"))
 		return 0;
-	uint32_t se;
-	return kLdsPerCu / compress_lds_bytes(win_bytes, p, 0, &se) < 4 ? 2 : 0;
+	uint32_t se, sh;
+	return kLdsPerCu / compress_lds_bytes(win_bytes, p, 0, &se, &sh) < 4 ? 2 : 0;
 }
 
 uint32_t frags_per_block(uint32_t max_in_len)
@@ -1388,7 +1413,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.win_bytes = ((max_in_len < kFragment ? max_in_len : kFragment) + 16 + 16 + 63) & ~63u;
 	const int placement = choose_placement(A.win_bytes, p);
 	const bool gtab = placement != 0;
-	size_t lds = compress_lds_bytes(A.win_bytes, p, placement, &A.s_entries);
+	size_t lds = compress_lds_bytes(A.win_bytes, p, placement, &A.s_entries, &A.s_shift);
 	if (const char *w = getenv("CSNAPPY_HIP_WGS_PER_CU")) {
 		/* experiments: cap the workgroups per CU by padding the LDS request */
 		const int k = atoi(w);
