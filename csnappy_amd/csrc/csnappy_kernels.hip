@@ -582,6 +582,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		uint32_t s = 1, qi = 0; /* scan start and index of the next scan probe */
 		uint32_t epoch = 0x03ffffffu;
 		bool fin = false;
+		const uint32_t chk0 = ((win_rd32<GWIN>(win32, wbase) * kHashMul) >> (shift - 1)) & 1u;
 
 		/* lane positions of a step; the 16 bytes at the lane's position are fetched one step
 		 * ahead (as soon as the cursor of the next step is known) to take that LDS round trip
@@ -641,7 +642,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t me1 = __builtin_amdgcn_alignbyte(raw[2], raw[1], rsh);
 			const uint32_t me2 = __builtin_amdgcn_alignbyte(raw[3], raw[2], rsh);
 			const uint32_t me3 = __builtin_amdgcn_alignbyte(raw[4], raw[3], rsh);
-			const uint32_t h = (me0 * kHashMul) >> shift;
+			const uint32_t prod = me0 * kHashMul;
+			const uint32_t h = prod >> shift;
+			/* The uint16 table entries hold 15-bit positions; bit 15 carries one more bit of the
+			 * hash product of the bytes at that position.  Equal 4 bytes imply equal products,
+			 * so a candidate whose check bit differs cannot match and its bytes need not be
+			 * fetched (an empty slot stands for position 0: its check bit is that of F[0..4)). */
+			const uint32_t chk = (prod >> (shift - 1)) & 1u;
 			/* slot sharing inside a step is detected with one or two small filters keyed by
 			 * different bits of the hash: a lane is cut only if BOTH report an earlier lane
 			 * (two lanes with the same slot collide in both; a false alarm needs two
@@ -677,9 +684,11 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				if (A.s_shift)
 					first_same = max(first_same, S2[key2] & 63u);
 			}
+			const bool maybe = (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
+			cand &= 0x7fffu;
 			cb[0] = cb[1] = cb[2] = cb[3] = 0;
 			if (GWIN) {
-				if ((int)lane < ulim) {
+				if ((int)lane < ulim && maybe) {
 					uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
 					__builtin_memcpy(&w4, win8 + wbase + cand, 16);
 					cb[0] = w4.x;
@@ -694,8 +703,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			 * 16 bytes away from every valid probe position) */
 			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
 			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
-			const uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
-					    : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
+			uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
+				      : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
+			if (!maybe)
+				mlen = 0;
 			if (!GTAB) {
 				const uint64_t cmask = __ballot(valid_c && first_same < lane);
 				const uint64_t imask = ~__ballot(valid_c);
@@ -878,7 +889,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			/* commit table[hash] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			if ((int)lane <= e_final && !inside)
-				tab[h] = (uint16_t)pos_c;
+				tab[h] = (uint16_t)(pos_c | (chk << 15));
 			wave_lds_fence();
 			if (PROF)
 				t_commit += __builtin_amdgcn_s_memtime() - t0;
