@@ -519,6 +519,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	/* ================================== PARSER ================================== */
 	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t_pub = 0, t0 = 0, t1 = 0;
 	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
+	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0;
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
 	uint4 *ring4 = reinterpret_cast<uint4 *>(ring);
@@ -802,6 +803,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 						i = (int)t;
 					}
 				}
+				if (PROF) {
+					tq = __builtin_amdgcn_s_memtime();
+					t_chain += tq - t1;
+				}
 				if (last >= 0) {
 					const int c_last = (int)rdlane(cl, last);
 					ip = p0_c + (uint32_t)c_last;
@@ -851,9 +856,19 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				const uint32_t emit1 = next_emit; /* literal start of a wide record */
 				if (stop == 66)
 					next_emit = ip;
+				if (PROF) {
+					const unsigned long long t = __builtin_amdgcn_s_memtime();
+					t_stop += t - tq;
+					tq = t;
+				}
 				/* the cursor of the next step is known: fetch its bytes now */
 				if (!fin)
 					place();
+				if (PROF) {
+					const unsigned long long t = __builtin_amdgcn_s_memtime();
+					t_place += t - tq;
+					tq = t;
+				}
 
 				/* ---- records of the taken matches, built by their own lanes ---- */
 				if (taken) {
@@ -881,6 +896,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				}
 				if (stop == 66)
 					add_record(emit1, wbase_l, wcnd, ip - wbase_l);
+				if (PROF)
+					t_rec += __builtin_amdgcn_s_memtime() - tq;
 			}
 			if (PROF) {
 				t0 = __builtin_amdgcn_s_memtime();
@@ -912,6 +929,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		atomicAdd(&A.prof[7], n_wide);
 		atomicAdd(&A.prof[8], n_sparse);
 		atomicAdd(&A.prof[9], 1ull);
+		atomicAdd(&A.prof[10], t_chain);
+		atomicAdd(&A.prof[11], t_stop);
+		atomicAdd(&A.prof[12], t_place);
+		atomicAdd(&A.prof[13], t_rec);
 	}
 }
 
