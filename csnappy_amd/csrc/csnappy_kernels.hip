@@ -1181,8 +1181,15 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			const uint32_t L = rdlane(l, t);
 			const uint8_t *ps = src + ip + t + rdlane(hsz, t);
 			uint8_t *pd = dst + op + rdlane(excl, t);
-			for (uint32_t j = lane; j < L; j += 64)
-				pd[j] = ps[j];
+			/* long literal: 16 B per lane per iteration (unaligned vector accesses), byte tail */
+			const uint32_t body = L & ~15u;
+			for (uint32_t j = lane * 16; j < body; j += 1024) {
+				uint4 v;
+				__builtin_memcpy(&v, ps + j, 16);
+				__builtin_memcpy(pd + j, &v, 16);
+			}
+			if (body + lane < L)
+				pd[body + lane] = ps[body + lane];
 		}
 		/* ---- pass 2: copies that read only what earlier batches produced ---- */
 		const bool cpy = exec_me && kind != 0;
