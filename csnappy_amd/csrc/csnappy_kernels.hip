@@ -1093,11 +1093,17 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	}
 
 	uint64_t op = 0; /* bytes produced */
+	uint64_t next8 = 0;     /* the 8 input bytes at the next iteration's ip + lane */
+	bool have_next = false; /* ... valid for every lane */
 	while (status == CSNAPPY_E_OK && ip < n) {
-		/* ---- every lane decodes the byte at ip+lane as if it were a tag ---- */
+		/* ---- every lane decodes the byte at ip+lane as if it were a tag ----
+		 * (the 8 bytes were requested at the end of the previous iteration when possible) */
 		const uint64_t at = ip + lane;
 		uint32_t b0 = 0, tr = 0;
-		if (at + 8 <= n) {
+		if (have_next) {
+			b0 = (uint32_t)next8 & 0xff;
+			tr = (uint32_t)(next8 >> 8);
+		} else if (at + 8 <= n) {
 			uint64_t v;
 			__builtin_memcpy(&v, src + at, 8);
 			b0 = (uint32_t)v & 0xff;
@@ -1141,6 +1147,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			cur += rdlane(esz, cl);
 		}
 		const bool istag = (tmask >> lane) & 1;
+		/* request the next iteration's bytes now; they arrive while this one's copies run */
+		have_next = ip + cur + 64 + 8 <= n;
+		if (have_next)
+			__builtin_memcpy(&next8, src + ip + cur + lane, 8);
 
 		/* ---- per-element checks, in the reference's order (Appendix C of SURVEY.md) ---- */
 		const bool trunc = at + hsz > n; /* header bytes cut off: reference is undefined, we say -5 */
@@ -1171,11 +1181,15 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask; /* elements to execute */
 		const bool exec_me = (run >> lane) & 1;
 
-		/* ---- pass 1: literals (SAW__Append / SAW__AppendFastPath, :264-293) ---- */
+		/* ---- passes 1+2 in one sweep, one lane per element: literals (SAW__Append /
+		 * SAW__AppendFastPath, :264-293) and copies that read only what earlier batches produced
+		 * (source ends in front of this batch's output) ---- */
 		const uint8_t *lsrc = src + at + hsz;
 		uint8_t *edst = dst + pb;
 		const bool lit = exec_me && kind == 0;
-		copy_exact(edst, lsrc, l, lit && l <= 64);
+		const bool cpy = exec_me && kind != 0;
+		const bool indep = cpy && off >= excl + l;
+		copy_exact(edst, lit ? lsrc : edst - off, l, (lit && l <= 64) || indep);
 		for (uint64_t big = __ballot(lit && l > 64); big; big &= big - 1) {
 			const uint32_t t = first_lane(big);
 			const uint32_t L = rdlane(l, t);
@@ -1191,10 +1205,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			if (body + lane < L)
 				pd[body + lane] = ps[body + lane];
 		}
-		/* ---- pass 2: copies that read only what earlier batches produced ---- */
-		const bool cpy = exec_me && kind != 0;
-		const bool indep = cpy && off >= excl + l;
-		copy_exact(edst, edst - off, l, indep);
 		/* ---- pass 3: the other copies, in order (SAW__AppendFromSelf, :295-317) ---- */
 		for (uint64_t dep = __ballot(cpy && !indep); dep; dep &= dep - 1) {
 			const uint32_t t = first_lane(dep);
