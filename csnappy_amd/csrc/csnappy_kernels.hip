@@ -1060,6 +1060,8 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
 
 extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(DecompressArgs A)
 {
+	/* 32-bit cursors: in_len and out_cap are uint32 in the reference API too; the batch API asks
+	 * for them to stay below 2^32 - 2^16 so that `cursor + lane + header` cannot wrap. */
 	const uint32_t lane = threadIdx.x;
 	const uint32_t blk = blockIdx.x;
 	const uint8_t *src = A.in + A.in_off[blk];
@@ -1067,8 +1069,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	uint8_t *dst = A.out + A.out_off[blk];
 	const uint32_t cap = A.out_cap[blk];
 
-	uint64_t ip = 0;
-	uint64_t limit = cap;
+	uint32_t ip = 0;
+	uint32_t limit = cap;
 	int32_t status = CSNAPPY_E_OK;
 
 	if (A.mode == CSNAPPY_HIP_STREAM) {
@@ -1092,13 +1094,13 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		limit = olen;
 	}
 
-	uint64_t op = 0; /* bytes produced */
+	uint32_t op = 0;        /* bytes produced */
 	uint64_t next8 = 0;     /* the 8 input bytes at the next iteration's ip + lane */
 	bool have_next = false; /* ... valid for every lane */
 	while (status == CSNAPPY_E_OK && ip < n) {
 		/* ---- every lane decodes the byte at ip+lane as if it were a tag ----
 		 * (the 8 bytes were requested at the end of the previous iteration when possible) */
-		const uint64_t at = ip + lane;
+		const uint32_t at = ip + lane;
 		uint32_t b0 = 0, tr = 0;
 		if (have_next) {
 			b0 = (uint32_t)next8 & 0xff;
@@ -1139,31 +1141,31 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 
 		/* ---- walk the real tag chain on the scalar unit ---- */
 		uint64_t tmask = 0;
-		uint64_t cur = 0;
-		const uint64_t room = n - ip; /* > 0 */
+		uint32_t cur = 0;
+		const uint32_t room = n - ip; /* > 0 */
 		while (cur < 64 && cur < room) {
-			const uint32_t cl = (uint32_t)cur;
-			tmask |= 1ull << cl;
-			cur += rdlane(esz, cl);
+			tmask |= 1ull << cur;
+			const uint32_t e = rdlane(esz, cur);
+			cur = cur + e < cur ? 0xffffffffu : cur + e; /* saturating */
 		}
 		const bool istag = (tmask >> lane) & 1;
 		/* request the next iteration's bytes now; they arrive while this one's copies run */
-		have_next = ip + cur + 64 + 8 <= n;
+		have_next = cur < room && room - cur >= 64 + 8;
 		if (have_next)
-			__builtin_memcpy(&next8, src + ip + cur + lane, 8);
+			__builtin_memcpy(&next8, src + (ip + cur + lane), 8);
 
 		/* ---- per-element checks, in the reference's order (Appendix C of SURVEY.md) ---- */
 		const bool trunc = at + hsz > n; /* header bytes cut off: reference is undefined, we say -5 */
-		const uint64_t avail = trunc ? 0 : n - (at + hsz);
+		const uint32_t avail = trunc ? 0 : n - (at + hsz);
 		const bool lit_short = kind == 0 && (int32_t)l >= 0 && avail < l; /* :374-375 */
 		const bool lit_neg = kind == 0 && (int32_t)l < 0;
 		const bool inbad = trunc || lit_short || lit_neg;
 		const uint32_t eff = (istag && !inbad) ? l : 0;
 		const uint32_t excl = wave_incl_scan_dpp(eff) - eff;
-		const uint64_t pb = op + excl; /* bytes produced before this element */
+		const uint32_t pb = op + excl; /* bytes produced before this element */
 		int32_t err = 0;
 		if (istag) {
-			const bool overrun = limit - pb < (uint64_t)l;
+			const bool overrun = limit - pb < l;
 			if (trunc)
 				err = CSNAPPY_E_DATA_MALFORMED;
 			else if (kind == 0)
@@ -1172,8 +1174,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				      : lit_neg ? CSNAPPY_E_DATA_MALFORMED
 						: 0;
 			else
-				err = (off == 0 || (uint64_t)off > pb) ? CSNAPPY_E_DATA_MALFORMED /* :301-303 */
-				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN		       /* :311-312 */
+				err = (off == 0 || off > pb) ? CSNAPPY_E_DATA_MALFORMED /* :301-303 */
+				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN	     /* :311-312 */
 						: 0;
 		}
 		const uint64_t emask = __ballot(err != 0);
@@ -1184,7 +1186,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		/* ---- passes 1+2 in one sweep, one lane per element: literals (SAW__Append /
 		 * SAW__AppendFastPath, :264-293) and copies that read only what earlier batches produced
 		 * (source ends in front of this batch's output) ---- */
-		const uint8_t *lsrc = src + at + hsz;
+		const uint8_t *lsrc = src + (at + hsz);
 		uint8_t *edst = dst + pb;
 		const bool lit = exec_me && kind == 0;
 		const bool cpy = exec_me && kind != 0;
@@ -1193,8 +1195,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		for (uint64_t big = __ballot(lit && l > 64); big; big &= big - 1) {
 			const uint32_t t = first_lane(big);
 			const uint32_t L = rdlane(l, t);
-			const uint8_t *ps = src + ip + t + rdlane(hsz, t);
-			uint8_t *pd = dst + op + rdlane(excl, t);
+			const uint8_t *ps = src + (ip + t + rdlane(hsz, t));
+			uint8_t *pd = dst + (op + rdlane(excl, t));
 			/* long literal: 16 B per lane per iteration (unaligned vector accesses), byte tail */
 			const uint32_t body = L & ~15u;
 			for (uint32_t j = lane * 16; j < body; j += 1024) {
@@ -1209,26 +1211,26 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		for (uint64_t dep = __ballot(cpy && !indep); dep; dep &= dep - 1) {
 			const uint32_t t = first_lane(dep);
 			const uint32_t L = rdlane(l, t), OFF = rdlane(off, t);
-			uint8_t *pd = dst + op + rdlane(excl, t);
+			uint8_t *pd = dst + (op + rdlane(excl, t));
 			if (lane < L) {
 				const uint32_t j = lane < OFF ? lane : lane % OFF;
-				pd[lane] = pd[(int64_t)j - (int64_t)OFF];
+				pd[lane] = pd[(int32_t)(j - OFF)];
 			}
 		}
 		if (run) {
 			const uint32_t t = 63u - (uint32_t)__builtin_clzll(run); /* last executed element */
-			op += (uint64_t)rdlane(excl, t) + rdlane(l, t);
+			op += rdlane(excl, t) + rdlane(l, t);
 		}
 		if (fe < 64) {
 			status = (int32_t)rdlane((uint32_t)err, fe);
 			break;
 		}
-		ip += cur;
+		ip = cur >= room ? n : ip + cur;
 	}
 
 	if (lane == 0) {
 		A.status[blk] = status;
-		A.produced[blk] = status == CSNAPPY_E_OK ? (uint32_t)op : 0;
+		A.produced[blk] = status == CSNAPPY_E_OK ? op : 0;
 	}
 }
 

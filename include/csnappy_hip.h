@@ -69,7 +69,8 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
  *                   csnappy_decompress_noheader
  *   d_status[b]     CSNAPPY_E_* code the reference call would return (0, -1, -2, -3, -5)
  *   d_produced[b]   bytes produced when status is 0 (FRAGMENT: *dst_len on exit), else 0
- * Bytes of the output slot beyond `produced` are never written.
+ * Bytes of the output slot beyond `produced` are never written.  in_len[b] and out_cap[b] must
+ * be below 2^32 - 2^16 (the kernels keep 32-bit cursors like the reference's uint32 API).
  */
 int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 				 const uint32_t *d_in_len, uint32_t nblocks, void *d_out,
