@@ -14,19 +14,20 @@
  *                               csnappy_get_uncompressed_length / csnappy_decompress :45-71,394-411
  *
  * Design (DESIGN.md has the long form):
- *   - compress: ONE WAVE PER 32 KiB FRAGMENT.  The fragment window and the uint16 hash table
- *     live in LDS.  The reference's probe loop is a sequential recurrence; we evaluate 64
- *     consecutive probe positions of that recurrence per step (one per lane), resolve the
- *     only intra-step dependency (two lanes with the same hash slot) exactly by truncating the
- *     step at the first such lane, and take the first lane whose candidate matches.  The
- *     result is bit-identical to the sequential loop.  Match extension compares 512 B per
- *     step across the wave.  Emission is deferred: (literal, copy) records are queued in LDS
- *     and 64 of them are encoded at once with a wave prefix sum for the output offsets.
- *   - decompress: one wave per block; 64 candidate tag positions are decoded in parallel,
- *     the true tag chain is walked on the scalar unit with v_readlane, per-element output
- *     offsets come from a wave prefix sum, errors are resolved in element order, then the
- *     elements are executed with wave-wide copies.
- *   - no MFMA: this is byte/integer work bound by LDS latency and HBM, not a contraction.
+ *   - compress: one workgroup of two waves per 32 KiB fragment.  The PARSER wave reproduces the
+ *     reference's sequential probe loop exactly, 64 consecutive positions per step: every lane
+ *     hashes its 4 bytes, gathers table[h], measures a lane-local match length against its
+ *     candidate; the step is cut at the first lane that shares a hash slot with an earlier lane
+ *     (the only way a lane's table read could be stale), and the chain of copies through the
+ *     step is followed on the scalar unit.  The EMITTER wave encodes the queued (literal, copy)
+ *     records and writes them out with aligned 16 B/lane stores.  The hash table and the window
+ *     live in LDS when at least four fragments fit a CU that way, else in global memory.
+ *   - decompress: one wave per block; 64 candidate tag positions are decoded in parallel, the
+ *     true tag chain is walked on the scalar unit with v_readlane, per-element output offsets
+ *     come from a DPP prefix sum, errors are resolved in element order, then literals and
+ *     independent copies run one lane per element and dependent copies wave-wide in order.
+ *   - no MFMA: this is byte/integer work bound by latency and cache-line gathers, not a
+ *     contraction.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

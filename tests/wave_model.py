@@ -1,12 +1,16 @@
 """Lane-level model of the compress kernel's step logic (TEST INFRASTRUCTURE).
 
-`snappy_compress_fragments` (csnappy_amd/csrc/csnappy_kernels.hip) evaluates 64 probe positions
-of the reference's sequential probe loop per step and truncates the step at the first lane that
-shares a hash slot with an earlier lane.  This file restates exactly that step logic in plain
-Python, lane by lane, so the claim "the wave-step algorithm is bit-identical to the sequential
-loop of csnappy_compress.c:469-606" can be fuzzed against the oracle on the CPU, where there is
-no GPU.  It models the ALGORITHM (roles, conflict truncation, state update, record queue,
-EmitCopy chunking); the HIP code is a SIMT transcription of it.
+`snappy_compress_fragments` (csnappy_amd/csrc/csnappy_kernels.hip) evaluates 64 positions of the
+reference's sequential probe loop per step and truncates the step at the first lane that shares
+a hash slot with an earlier lane.  This file restates that step logic in plain Python, lane by
+lane, so the claim "the wave-step algorithm is bit-identical to the sequential loop of
+csnappy_compress.c:469-606" can be fuzzed against the oracle on the CPU, where there is no GPU.
+It models the ALGORITHM (lane roles, conflict truncation, the chain of copies through a step,
+cursor update, EmitCopy chunking); the HIP code is a SIMT transcription of it.
+
+  compress_fragment      v1: one match per step (the first GPU version; kept as the simplest
+                         statement of the truncation argument)
+  compress_fragment_v2   dense multi-match steps + sparse steps: what the kernel runs today
 """
 import struct
 
