@@ -234,6 +234,22 @@ def test_wave_step_model_is_bit_exact(port, urls):
                 (len(x), p, s_entries)
 
 
+def test_dense_multi_match_step_model_is_bit_exact(port, urls):
+    """v2 of the model = what the kernel runs: dense steps that retire several copies, sparse
+    steps after 32 fruitless probes, any lane-local match cap, any (even tiny) conflict filter."""
+    import wave_model as wm
+    frag = urls[200000:200000 + 32768]
+    for p in (16, 15, 12):
+        assert wm.compress_fragment_v2(frag, p) == port.compress_fragment(frag, p)
+    rng = np.random.default_rng(8)
+    for x, p in _fuzz_inputs(4, 160, 6000):
+        x = x[:32768]
+        s_entries = int(rng.choice([4, 64, min(1 << (p - 1), 1024)]))
+        lm = int(rng.choice([4, 8, 16]))
+        assert wm.compress_fragment_v2(x.tobytes(), p, s_entries, lm=lm) == port.compress_fragment(x, p), \
+            (len(x), p, s_entries, lm)
+
+
 # ---- batch drivers used by the GPU parity tests and the CPU baseline --------------------------
 def test_batch_drivers_match_single_calls(port, urls):
     b = api.Batch.uniform(len(urls), 65536, device=None)
