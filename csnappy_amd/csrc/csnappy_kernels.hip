@@ -609,8 +609,11 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				pos = 0;
 			rsh = wbase + pos;
 			if (GWIN) {
-				uint4 v; /* valid lanes have 16 bytes of fragment at pos (pos <= n - 16) */
-				__builtin_memcpy(&v, win8 + rsh, 16);
+				/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others must
+				 * not read at all: the input may end right behind a 15-byte fragment */
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (valid)
+					__builtin_memcpy(&v, win8 + rsh, 16);
 				raw[0] = v.x;
 				raw[1] = v.y;
 				raw[2] = v.z;
