@@ -283,3 +283,153 @@ def compress_fragment_v2(F, p, s_entries=None, stats=None, lm=LM):
     if next_emit < n:
         records.append((next_emit, n - next_emit, 0, 0))
     return encode_records(F, records)
+
+
+# =================================================================================================
+# v3: v2 + optimistic walks.  A lane that shares a hash slot with an earlier lane only matters if
+# BOTH lanes are actually probed / inserted by the chain; lanes inside a copy never are.  So the
+# chain is first walked over all valid lanes, then the lanes it really inserted are checked for
+# slot sharing among themselves, and only if such a lane x exists is the walk redone with the step
+# cut at x.  Repetitive data (runs, small-integer words) otherwise collapses to steps of a few
+# positions because neighbouring positions inside a run share their slot.
+# =================================================================================================
+def compress_fragment_v3(F, p, s_entries=None, stats=None, lm=LM):
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 64
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    if s_entries is None:
+        s_entries = min(1 << (p - 1), 1024)
+    smask = s_entries - 1
+    records = []
+    next_emit = 0
+
+    def lcp(a, b, start, limit):
+        k = start
+        while k < limit and F[a + k] == F[b + k]:
+            k += 1
+        return k
+
+    if n >= MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        cur = dict(ip=0, spec=0, s=1, qi=0)
+        fin = False
+        while not fin:
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            ip, spec, s, qi = cur["ip"], cur["spec"], cur["s"], cur["qi"]
+            sparse = spec == 0 and qi >= 32
+            p0 = ip - 1 if spec == 2 else ip if spec == 1 else s + qi
+            pos, valid = [0] * WAVE, [False] * WAVE
+            for l in range(WAVE):
+                if sparse:
+                    pos[l] = scan_pos(s, qi + l)
+                    valid[l] = scan_pos(s, qi + l + 1) <= ip_limit
+                else:
+                    pos[l] = p0 + l
+                    valid[l] = pos[l] + 1 <= ip_limit
+                if not valid[l]:
+                    pos[l] = 0
+            w = [rd32(pos[l]) for l in range(WAVE)]
+            h = [((w[l] * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            key = [h[l] & smask for l in range(WAVE)]
+            cand = [tab[h[l]] for l in range(WAVE)]
+            mlen = [lcp(cand[l], pos[l], 0, lm) if valid[l] else 0 for l in range(WAVE)]
+            v = next((l for l in range(WAVE) if not valid[l]), 64)
+            seen = set()
+            any_share = False
+            for l in range(v):
+                if key[l] in seen:
+                    any_share = True
+                seen.add(key[l])
+
+            def walk(ulim):
+                """-> (new records, new cursor, fin, e_final, inserted lanes); no side effects"""
+                recs, c = [], dict(cur)
+                ne = next_emit
+                match = [l < ulim and mlen[l] >= 4 for l in range(WAVE)]
+                hole = set()
+                done = False
+                if sparse:
+                    if not any(match):
+                        e_final = ulim - 1
+                        if ulim == v and v < 64:
+                            done = True
+                        else:
+                            c["qi"] = qi + ulim
+                    else:
+                        i = match.index(True)
+                        e_final = i
+                        base, cnd, L = pos[i], cand[i], mlen[i]
+                        if L == lm and base + L < n:
+                            L = lcp(cnd, base, lm, n - base)
+                        recs.append((ne, base - ne, base - cnd, L))
+                        c["ip"] = base + L
+                        ne = base + L
+                        if base + L >= ip_limit:
+                            done = True
+                        c["spec"] = 2
+                else:
+                    if spec == 2:
+                        a, zl, seg_s = 1, 2, ip + 1
+                    elif spec == 1:
+                        a, zl, seg_s = 0, 1, ip + 1
+                    else:
+                        a, zl, seg_s = 0, -qi, s
+                    lim = zl + 31
+                    while True:
+                        i = next((l for l in range(a, 64) if match[l]), 64)
+                        if i > lim or i > 63:
+                            e = min(lim, ulim - 1)
+                            e_final = e
+                            if ulim == v and v <= lim and v < 64:
+                                done = True
+                            elif e < a:
+                                c["spec"] = 1
+                                e_final = 0
+                            else:
+                                c["spec"], c["s"], c["qi"] = 0, seg_s, e + 1 - zl
+                            break
+                        cnd, L, base, wide = cand[i], mlen[i], p0 + i, False
+                        if L == lm and base + L < n:
+                            wide, L = True, lcp(cnd, base, lm, n - base)
+                        recs.append((ne, base - ne, base - cnd, L))
+                        c["ip"] = base + L
+                        ne = base + L
+                        e_final = i
+                        cc = i + L
+                        if base + L >= ip_limit:
+                            done = True
+                            break
+                        if wide or cc >= ulim:
+                            c["spec"] = 2
+                            break
+                        for l in range(i + 1, cc - 1):
+                            hole.add(l)
+                        a, zl, lim, seg_s = cc, cc + 1, cc + 32, base + L + 1
+                ins = [l for l in range(0, e_final + 1) if l not in hole]
+                return recs, c, done, ne, ins
+
+            ulim = v
+            recs, c, done, ne, ins = walk(ulim)
+            if any_share:
+                seen = set()
+                x = None
+                for l in ins:
+                    if key[l] in seen:
+                        x = l
+                        break
+                    seen.add(key[l])
+                if x is not None:
+                    if stats is not None:
+                        stats["rewalk"] = stats.get("rewalk", 0) + 1
+                    recs, c, done, ne, ins = walk(x)
+            records += recs
+            cur, fin, next_emit = c, done, ne
+            for l in ins:
+                tab[h[l]] = pos[l]
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
