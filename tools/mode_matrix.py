@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for wl, ps in (("text", (16, 15, 14)), ("urls", (16, 15)), ("low", (16,)), ("page", (13,))):
     for p in ps:
-        for mode in ("lds", "global"):
+        for mode in ("lds", "global", "gwin"):
             env = dict(os.environ, CSNAPPY_HIP_TABLE=mode)
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                                   "--no-cpu-baseline", "--workload", wl, "--p", str(p), "--gib", "0.5"],
