@@ -520,7 +520,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	/* ================================== PARSER ================================== */
 	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t_pub = 0, t0 = 0, t1 = 0;
 	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
-	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0;
+	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0, t_pre = 0, t_loop_end = 0;
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
 	uint4 *ring4 = reinterpret_cast<uint4 *>(ring);
@@ -630,6 +630,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 		};
 		place();
+		if (PROF)
+			t_pre = __builtin_amdgcn_s_memtime() - t_begin;
 
 		while (!fin) {
 			if (PROF) {
@@ -917,6 +919,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		}
 	}
 
+	if (PROF)
+		t_loop_end = __builtin_amdgcn_s_memtime();
 	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
 	if (next_emit < n)
 		add_record(next_emit, n, n, 0);
@@ -937,6 +941,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		atomicAdd(&A.prof[11], t_stop);
 		atomicAdd(&A.prof[12], t_place);
 		atomicAdd(&A.prof[13], t_rec);
+		atomicAdd(&A.prof[14], t_pre);
+		atomicAdd(&A.prof[15], t_end - t_loop_end);
 	}
 }
 

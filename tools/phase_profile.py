@@ -32,5 +32,5 @@ print("table mode:", os.environ.get("CSNAPPY_HIP_TABLE", "lds"))
 print(f"fragments {nf}  steps/frag {v[5]/nf:.1f}  matches/frag {v[6]/nf:.1f}  wide/frag {v[7]/nf:.1f}  sparse/frag {v[8]/nf:.1f}")
 for i, n in enumerate(names):
     print(f"  {n:8s} {v[i]/nf:12.0f} ticks/frag   {v[i]/max(v[5],1):9.1f} per step   {v[i]/max(v[6],1):9.1f} per match")
-for i, n in ((10, "w.chain"), (11, "w.stop"), (12, "w.place"), (13, "w.records")):
+for i, n in ((10, "w.chain"), (11, "w.stop"), (12, "w.place"), (13, "w.records"), (14, "pre-loop"), (15, "post-loop")):
     print(f"  {n:9s} {v[i]/nf:11.0f} ticks/frag   {v[i]/max(v[5],1):9.1f} per step")
