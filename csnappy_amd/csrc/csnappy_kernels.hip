@@ -299,6 +299,10 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	uint32_t *ring = S + (A.s_shift ? 2 : 1) * A.s_entries; /* [2][64] records {lit_start, base, cand, copy_len} */
 	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
 	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
+	/* GTAB: one bit per table slot, "written in this fragment".  A clear bit means the slot is
+	 * empty (the reference's zeroed table: candidate position 0) without touching memory, so the
+	 * global table is never cleared and never gathered for empty slots (41-50 % of the probes). */
+	uint32_t *occ = reinterpret_cast<uint32_t *>(stage + kStageBytes);
 	const uint32_t smask = A.s_entries - 1;
 
 	/* window: aligned 16 B chunks; byte i of the fragment sits at win8[wbase + i] */
@@ -311,9 +315,15 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	}
 	if (n >= kMargin) {
 		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
-		uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-		for (uint32_t k = tid; k < ((1u << ws) >> 4); k += 128)
-			t4[k] = make_uint4(0, 0, 0, 0);
+		if (GTAB) {
+			uint4 *o4 = reinterpret_cast<uint4 *>(occ);
+			for (uint32_t k = tid; k < ((1u << ws) >> 8); k += 128) /* 2^(ws-1) bits = 2^(ws-4) bytes */
+				o4[k] = make_uint4(0, 0, 0, 0);
+		} else {
+			uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+			for (uint32_t k = tid; k < ((1u << ws) >> 4); k += 128)
+				t4[k] = make_uint4(0, 0, 0, 0);
+		}
 		uint4 *s4 = reinterpret_cast<uint4 *>(S);
 		for (uint32_t k = tid; k < (((A.s_shift ? 2 : 1) * A.s_entries) >> 2); k += 128)
 			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -682,7 +692,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				c1 = min(c1, (int)A.width);
 				v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
 				ulim = min(c1, v);
-				if ((int)lane < ulim)
+				if ((int)lane < ulim && ((occ[h >> 5] >> (h & 31)) & 1u))
 					cand = tab[h];
 			} else {
 				cand = tab[h];
@@ -911,8 +921,11 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			/* commit table[hash] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
-			if ((int)lane <= e_final && !inside)
+			if ((int)lane <= e_final && !inside) {
 				tab[h] = (uint16_t)(pos_c | (chk << 15));
+				if (GTAB)
+					atomicOr(&occ[h >> 5], 1u << (h & 31));
+			}
 			wave_lds_fence();
 			if (PROF)
 				t_commit += __builtin_amdgcn_s_memtime() - t0;
@@ -1339,7 +1352,7 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
  * global memory */
 size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries, uint32_t *s_shift)
 {
-	uint32_t s_cap = placement == 1 ? 512u : 1024u;
+	uint32_t s_cap = placement ? 512u : 1024u; /* global placements: two 512-entry filters */
 	if (const char *e = getenv("CSNAPPY_HIP_S_ENTRIES")) /* experiments */
 		s_cap = (uint32_t)atoi(e);
 	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
@@ -1353,7 +1366,7 @@ size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_
 		*s_shift = 0;
 	return (size_t)(placement == 2 ? 0 : win_bytes) + (placement ? 0 : ((size_t)1 << p)) +
 	       (size_t)*s_entries * 4 * (*s_shift ? 2 : 1) +
-	       kRingBytes + kStageBytes;
+	       kRingBytes + kStageBytes + (placement ? ((size_t)1 << p) >> 4 : 0);
 }
 
 /* Where the hash table and the window live.  In LDS they are one round trip closer, but a
