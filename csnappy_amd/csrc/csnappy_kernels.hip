@@ -235,7 +235,7 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  *                step ends at its first match.
  * ======================================================================================== */
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
-constexpr uint32_t kBigRecord = 40;   /* records encoding to more than this bypass the staging */
+constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging */
 constexpr uint32_t kFlushAt = 512;   /* staged bytes that trigger a coalesced flush */
 constexpr uint32_t kStageBytes = 16 + kFlushAt + 64 * kBigRecord + 16; /* LDS output staging */
 constexpr uint32_t kRingBytes = 2 * 64 * 16 + 16; /* two batches of 64 records (4 dwords each) + two count words */
