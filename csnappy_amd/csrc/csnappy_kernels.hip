@@ -240,11 +240,6 @@ constexpr uint32_t kFlushAt = 512;   /* staged bytes that trigger a coalesced fl
 constexpr uint32_t kStageBytes = 16 + kFlushAt + 64 * kBigRecord + 16; /* LDS output staging */
 constexpr uint32_t kRingBytes = 2 * 64 * 16 + 16; /* two batches of 64 records (4 dwords each) + two count words */
 
-DEVINL uint64_t lane_range(int a, int e) /* bits a..e inclusive, 0 <= a <= e <= 63 */
-{
-	return ((~0ull) >> (63 - e)) & ((~0ull) << a);
-}
-
 /* 16 bytes at an arbitrary byte index of LDS as four little-endian dwords */
 DEVINL void lds_rd128(const uint32_t *w, uint32_t byte, uint32_t out[4])
 {
