@@ -498,3 +498,29 @@ def test_legacy_api_large_single_stream_and_threads(torch, chk):
     [t.join() for t in ts]
     assert not errs, errs
     assert got == want
+
+
+def test_rccl_gather_of_the_compacted_stream_single_rank(torch, urls):
+    """The only collective of the path (assembling the final stream) over RCCL with one rank: the
+    gathered bytes equal the concatenation of the per-block outputs."""
+    import socket
+    import torch.distributed as dist
+    from csnappy_amd import shard
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        data = np.frombuffer(urls, dtype=np.uint8)
+        lens = api.Batch.uniform(len(urls), 65536, device=None).in_len
+        blocks, b, d_out = gpu_compress(torch, data, lens, 16, api.STREAM)
+        dense, _ = shard.compact(d_out, b.d_out_off, b.d_out_len)
+        parts, sizes = shard.gather_streams(dense, dist, 1)
+        torch.cuda.synchronize()
+        assert sizes == [sum(len(x) for x in blocks)]
+        assert bytes(parts[0].cpu().numpy()) == b"".join(blocks)
+        assert sha(b"".join(blocks)) == GOLD["urls_blocks"]["64k_p16"]["sha256"]
+    finally:
+        dist.destroy_process_group()
