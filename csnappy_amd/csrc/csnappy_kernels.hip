@@ -672,22 +672,26 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				if (A.s_shift)
 					atomicMin(&S2[key2], (epoch << 6) | lane);
 			}
+			/* A lane that shares its slot with an earlier lane of the step ("flagged") cannot trust
+			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
+			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
 			uint32_t cand = 0, first_same;
 			int c1, v, ulim;
+			uint64_t cmask; /* flagged lanes */
 			if (GTAB) {
 				/* the table (and window) gathers go to L2/HBM: resolve the slot sharing first
-				 * (LDS only) so that lanes behind the cut do not gather at all */
+				 * (LDS only) so that flagged lanes and lanes behind a cut do not gather at all */
 				wave_lds_fence();
 				first_same = S[key] & 63u; /* lowest valid lane with my slot key */
 				if (A.s_shift)
 					first_same = max(first_same, S2[key2] & 63u);
-				const uint64_t cmask = __ballot(valid_c && first_same < lane);
+				const bool flagged = valid_c && first_same < lane;
+				cmask = __ballot(flagged);
 				const uint64_t imask = ~__ballot(valid_c);
 				c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
-				c1 = min(c1, (int)A.width);
 				v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
-				ulim = min(c1, v);
-				if ((int)lane < ulim && ((occ[h >> 5] >> (h & 31)) & 1u))
+				ulim = sparse_c ? min(c1, v) : min(v, (int)A.width);
+				if ((int)lane < ulim && !flagged && ((occ[h >> 5] >> (h & 31)) & 1u))
 					cand = tab[h];
 			} else {
 				cand = tab[h];
@@ -700,7 +704,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			cand &= 0x7fffu;
 			cb[0] = cb[1] = cb[2] = cb[3] = 0;
 			if (GWIN) {
-				if ((int)lane < ulim && maybe) {
+				if ((int)lane < ulim && maybe && !((cmask >> lane) & 1)) {
 					uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
 					__builtin_memcpy(&w4, win8 + wbase + cand, 16);
 					cb[0] = w4.x;
@@ -720,11 +724,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			if (!maybe)
 				mlen = 0;
 			if (!GTAB) {
-				const uint64_t cmask = __ballot(valid_c && first_same < lane);
+				cmask = __ballot(valid_c && first_same < lane);
 				const uint64_t imask = ~__ballot(valid_c);
 				c1 = cmask ? (int)first_lane(cmask) : 64;
 				v = imask ? (int)first_lane(imask) : 64;
-				ulim = min(c1, v);
+				ulim = sparse_c ? min(c1, v) : v;
+			} else if ((cmask >> lane) & 1) {
+				mlen = 0; /* nothing was gathered for a flagged lane */
 			}
 			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
 			epoch--;
@@ -736,7 +742,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			int e_final;            /* last lane whose table write is committed */
 			bool inside = false;    /* dense: this lane lies strictly inside a taken copy */
 			uint64_t taken = 0;     /* dense: lanes whose match is part of the chain */
-			const uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
+			uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
 			const uint32_t emit0 = next_emit;
 			const uint32_t nev0 = nev;
 			if (sparse_c) {
@@ -770,14 +776,27 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				 * nx = the next match lane of the chain if my match is taken:
 				 *      64 -> the re-match probe falls outside the usable lanes (step ends, spec 2)
 				 *      65 -> none of the 33 probes after my match (re-match + 32 scan) matches */
+				/* flagged lanes are stops of the chain like matches: what they hold is decided
+				 * when (and if) the chain gets there */
+				uint64_t flagmask = ulim < 64 ? cmask & ((1ull << ulim) - 1) : cmask;
+				const uint64_t stopmask = matchmask | flagmask;
 				uint32_t nx;
-				{
-					const uint64_t rest = cl < 64 ? matchmask >> cl : 0;
+				auto next_stop = [&]() {
+					const uint64_t rest = cl < 64 ? stopmask >> cl : 0;
 					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
 					const uint32_t j = cl + fm;
 					nx = (int)cl >= ulim ? 64u : (fm <= 32 && j <= 63) ? j : 65u;
-				}
-				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
+				};
+				next_stop();
+				uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
+				uint64_t special = widemask | flagmask;
+				/* lanes strictly inside a copy of the chain so far (never probed, never inserted) */
+				auto inside_of = [&](uint64_t tk) -> bool {
+					const uint64_t below = tk & lt_mask;
+					const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+					return below != 0 && lane + 1 < cprev;
+				};
 				int a, zl;      /* first lane that may probe, lane of scan index 0 */
 				uint32_t seg_s; /* scan start of the current segment */
 				if (spec == 2) {
@@ -794,13 +813,56 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 					seg_s = s;
 				}
 				int lim = zl + 31; /* last lane whose probe is still one of the 32 stride-1 probes */
-				const uint64_t m0 = matchmask & ((~0ull) << a);
+				const uint64_t m0 = stopmask & ((~0ull) << a);
 				int i = m0 ? (int)first_lane(m0) : 64;
 				int last = -1;
 				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
 				if (i <= lim && i <= 63) {
 					for (;;) {
-						if ((widemask >> i) & 1) {
+						if ((special >> i) & 1) {
+							if ((flagmask >> i) & 1) {
+								/* ---- the chain probes a flagged lane ----
+								 * Its candidate is the latest position inserted for its slot: the
+								 * highest lane below it that this step inserts and that has the same
+								 * hash -- whose bytes are that lane's own 16 bytes -- else the table
+								 * value.  (Global placements did not gather the latter: cut here.) */
+								flagmask &= ~(1ull << i);
+								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(inside_of(taken));
+								const uint64_t same = __ballot(h == rdlane(h, i)) & ins;
+								if (same) {
+									const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
+									const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
+									const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
+									const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
+									const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
+									const uint32_t ml = ylo ? (uint32_t)(__builtin_ctzll(ylo) >> 3)
+											: yhi ? 8u + (uint32_t)(__builtin_ctzll(yhi) >> 3) : 16u;
+									if ((int)lane == i) {
+										cand = p0_c + j;
+										mlen = ml;
+									}
+								} else if (GTAB) {
+									ulim = i;
+									stop = last < 0 ? 67u : (int)rdlane(cl, last) >= i ? 64u : 65u;
+									break;
+								}
+								cl = lane + mlen;
+								next_stop();
+								widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
+								special = widemask | flagmask;
+								if (rdlane(mlen, i) >= 4)
+									continue; /* a match: take it (or extend it) like any other */
+								/* no match: on to the next stop of the current segment */
+								const int lim_cur = last >= 0 ? (int)rdlane(cl, last) + 32 : lim;
+								const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
+								const int i2 = m ? (int)first_lane(m) : 64;
+								if (i2 <= lim_cur && i2 <= 63) {
+									i = i2;
+									continue;
+								}
+								stop = last >= 0 ? 65u : 67u;
+								break;
+							}
 							stop = 66;
 							break;
 						}
@@ -916,7 +978,22 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			/* commit table[hash] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
-			if ((int)lane <= e_final && !inside) {
+			bool commit = (int)lane <= e_final && !inside;
+			{
+				/* of several committed lanes with one slot only the last may write (flagged lanes
+				 * that the chain inserted; sparse steps never commit one) */
+				const uint64_t cm = __ballot(commit);
+				uint64_t fl = cmask & cm;
+				uint64_t dead = 0;
+				while (fl) {
+					const uint32_t x = first_lane(fl);
+					fl &= fl - 1;
+					dead |= __ballot(h == rdlane(h, x)) & cm & ((1ull << x) - 1);
+				}
+				if ((dead >> lane) & 1)
+					commit = false;
+			}
+			if (commit) {
 				tab[h] = (uint16_t)(pos_c | (chk << 15));
 				if (GTAB)
 					atomicOr(&occ[h >> 5], 1u << (h & 31));

@@ -429,6 +429,46 @@ def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
     assert sha(b"".join(blocks)) == g["sha256"]
 
 
+def _slot_sharing_cases(seed, count):
+    """Inputs whose 64-position steps are full of lanes with one hash slot: short periods, words on
+    a fixed stride, few-symbol alphabets, sparse non-zero bytes (heap-like pages)."""
+    rng = np.random.default_rng(seed)
+    for k in range(count):
+        n = int(rng.choice([rng.integers(16, 400), rng.integers(400, 9000), 32768, 65536]))
+        kind = k % 5
+        if kind == 0:  # period 1..63
+            x = np.resize(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8), n)
+        elif kind == 1:  # period with a few mutations
+            x = np.resize(rng.integers(0, 4, int(rng.integers(4, 40)), dtype=np.uint8), n).copy()
+            x[rng.integers(0, n, max(n // 97, 1))] ^= 1
+        elif kind == 2:  # 8-byte records with a counter byte (heap / struct arrays)
+            x = np.zeros(n, np.uint8)
+            x[::8] = (np.arange(len(x[::8])) >> int(rng.integers(0, 4))).astype(np.uint8)
+            x[4::8][:len(x[4::8])] = rng.integers(0, 2, len(x[4::8]), dtype=np.uint8)
+        elif kind == 3:  # words from a tiny dictionary
+            words = [bytes(rng.integers(97, 101, int(rng.integers(2, 7)), dtype=np.uint8)) for _ in range(6)]
+            buf = b"".join(words[int(i)] for i in rng.integers(0, 6, n // 2 + 1))
+            x = np.frombuffer(buf[:n], dtype=np.uint8).copy()
+        else:  # two-symbol noise
+            x = rng.integers(0, 2, n, dtype=np.uint8) * 255
+        yield x
+
+
+@pytest.mark.parametrize("placement", ["lds", "global", "gwin"])
+def test_slot_sharing_inside_a_step_is_resolved_exactly(torch, chk, placement, monkeypatch):
+    """Dense steps forward a flagged lane's candidate from an earlier lane of the same step (or cut
+    the step in the global placements): every placement, several table powers, both modes."""
+    monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+    xs = list(_slot_sharing_cases(77, 60))
+    for p, mode in ((16, api.STREAM), (12, api.STREAM), (9, api.STREAM), (13, api.FRAGMENT)):
+        ys = [x[:32768] for x in xs] if mode == api.FRAGMENT else xs
+        host, lens = np.concatenate(ys), [len(y) for y in ys]
+        blocks, _, _ = gpu_compress(torch, host, lens, p, mode)
+        want = oracle_blocks(chk, host, lens, p, mode)
+        bad = [i for i, (a, b) in enumerate(zip(blocks, want)) if a != b]
+        assert not bad, (placement, p, mode, bad[:5], [lens[i] for i in bad[:5]])
+
+
 # -------------------------------------------------------------------------------------------------
 # next-row f2: the reference's block_compressor page container (block_compressor.c:275-394) on the
 # batched FRAGMENT path

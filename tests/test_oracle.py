@@ -250,6 +250,31 @@ def test_dense_multi_match_step_model_is_bit_exact(port, urls):
             (len(x), p, s_entries, lm)
 
 
+def test_forwarding_step_model_is_bit_exact(port, urls):
+    """v4 of the model = dense steps that do not stop at a lane sharing its slot with an earlier
+    lane of the step: the lane's candidate is forwarded from that lane (table value / cut when there
+    is none).  Both variants the kernel instantiates (LDS table: table value; global table: cut)."""
+    import wave_model as wm
+    frag = urls[300000:300000 + 32768]
+    for p, fc in ((16, True), (13, False), (9, False)):
+        assert wm.compress_fragment_v4(frag, p, fallback_cut=fc) == port.compress_fragment(frag, p)
+    rng = np.random.default_rng(9)
+    k = 0
+    for x, p in _fuzz_inputs(6, 220, 5000):
+        x = x[:32768]
+        s_entries = int(rng.choice([4, 64, min(1 << (p - 1), 1024)]))
+        lm = int(rng.choice([4, 8, 16]))
+        k += 1
+        assert wm.compress_fragment_v4(x.tobytes(), p, s_entries, lm=lm, fallback_cut=bool(k & 1)) == \
+            port.compress_fragment(x, p), (len(x), p, s_entries, lm, k & 1)
+    # heap-like pages: most lanes of a step share slots
+    pages = api.generate_host(2, 0xC5A90004, 0, 48, 4096)
+    for i in range(48):
+        pg = pages[i * 4096:(i + 1) * 4096]
+        for fc in (False, True):
+            assert wm.compress_fragment_v4(bytes(pg), 13, fallback_cut=fc) == port.compress_fragment(pg, 13)
+
+
 # ---- batch drivers used by the GPU parity tests and the CPU baseline --------------------------
 def test_batch_drivers_match_single_calls(port, urls):
     b = api.Batch.uniform(len(urls), 65536, device=None)

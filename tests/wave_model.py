@@ -433,3 +433,174 @@ def compress_fragment_v3(F, p, s_entries=None, stats=None, lm=LM):
     if next_emit < n:
         records.append((next_emit, n - next_emit, 0, 0))
     return encode_records(F, records)
+
+
+# =================================================================================================
+# v4: v2 + in-step forwarding.  Instead of cutting the step at the first lane that shares a hash
+# slot with an earlier lane, the chain treats such flagged lanes as stops: when it arrives at one
+# that is about to be PROBED, the lane's candidate is patched to the latest earlier lane of this
+# step that was inserted and has the same hash (its bytes are that lane's own bytes -- no memory
+# access), else the table value stands.  Lanes inside copies are never probed and need nothing.
+# Inserted lanes that are superseded by a later inserted lane with the same hash do not commit.
+# =================================================================================================
+def compress_fragment_v4(F, p, s_entries=None, stats=None, lm=LM, fallback_cut=False):
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 64
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    if s_entries is None:
+        s_entries = min(1 << (p - 1), 1024)
+    smask = s_entries - 1
+    records = []
+    next_emit = 0
+
+    def lcp(a, b, start, limit):
+        k = start
+        while k < limit and F[a + k] == F[b + k]:
+            k += 1
+        return k
+
+    if n >= MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        ip, spec, s, qi = 0, 0, 1, 0
+        fin = False
+        while not fin:
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            sparse = spec == 0 and qi >= 32
+            p0 = ip - 1 if spec == 2 else ip if spec == 1 else s + qi
+            pos, valid = [0] * WAVE, [False] * WAVE
+            for l in range(WAVE):
+                if sparse:
+                    pos[l] = scan_pos(s, qi + l)
+                    valid[l] = scan_pos(s, qi + l + 1) <= ip_limit
+                else:
+                    pos[l] = p0 + l
+                    valid[l] = pos[l] + 1 <= ip_limit
+                if not valid[l]:
+                    pos[l] = 0
+            w = [rd32(pos[l]) for l in range(WAVE)]
+            h = [((w[l] * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            key = [h[l] & smask for l in range(WAVE)]
+            cand = [tab[h[l]] for l in range(WAVE)]
+            mlen = [lcp(cand[l], pos[l], 0, lm) if valid[l] else 0 for l in range(WAVE)]
+            v = next((l for l in range(WAVE) if not valid[l]), 64)
+            firstk = {}
+            flagged = [False] * WAVE  # has an earlier valid lane with the same filter key
+            for l in range(v):
+                if key[l] in firstk:
+                    flagged[l] = True
+                else:
+                    firstk[key[l]] = l
+            if sparse:
+                # sparse steps keep the simple cut
+                c_ = next((l for l in range(v) if flagged[l]), 64)
+                ulim = min(c_, v)
+                m = next((l for l in range(ulim) if mlen[l] >= 4), None)
+                if m is None:
+                    for l in range(ulim):
+                        tab[h[l]] = pos[l]
+                    if ulim == v and v < 64:
+                        break
+                    qi += ulim
+                    continue
+                for l in range(m + 1):
+                    tab[h[l]] = pos[l]
+                base, cnd = pos[m], cand[m]
+                L = mlen[m]
+                if L == lm and base + L < n:
+                    L = lcp(cnd, base, lm, n - base)
+                records.append((next_emit, base - next_emit, base - cnd, L))
+                ip = base + L
+                next_emit = ip
+                if ip >= ip_limit:
+                    break
+                spec, s, qi = 2, ip + 1, 0
+                continue
+
+            # ---- dense step with forwarding ----
+            ulim = v
+            ins = []      # inserted lanes in order
+            dead = set()  # inserted lanes superseded by a later inserted lane with the same hash
+
+            def insert(l):
+                for j in ins:
+                    if h[j] == h[l]:
+                        dead.add(j)
+                ins.append(l)
+
+            def patched(l):
+                """(candidate, match length) of lane l given the lanes inserted so far"""
+                if flagged[l]:
+                    js = [j for j in ins if h[j] == h[l]]
+                    if js:
+                        j = js[-1]
+                        if stats is not None:
+                            stats["fwd"] = stats.get("fwd", 0) + 1
+                        return pos[j], lcp(pos[j], pos[l], 0, lm)
+                    if fallback_cut:
+                        return None, None  # the table value was not gathered: cut the step here
+                return cand[l], mlen[l]
+
+            if spec == 2:
+                a, zl, seg_s = 1, 2, ip + 1
+                insert(0)
+            elif spec == 1:
+                a, zl, seg_s = 0, 1, ip + 1
+            else:
+                a, zl, seg_s = 0, -qi, s
+            lim = zl + 31
+            while True:
+                # probe lanes a.. in order until a match, the segment limit, or the end of the step
+                i, found = a, None
+                while i <= min(lim, ulim - 1, 63):
+                    cnd, L = patched(i)
+                    if cnd is None:
+                        ulim = i
+                        if stats is not None:
+                            stats["cuts"] = stats.get("cuts", 0) + 1
+                        break
+                    insert(i)
+                    if L >= 4:
+                        found = (i, cnd, L)
+                        break
+                    i += 1
+                if found is None:
+                    e = min(lim, ulim - 1)
+                    if ulim == v and v <= lim and v < 64:
+                        fin = True
+                    elif e < a:
+                        # only the ip-1 insert (or nothing) was usable
+                        if spec == 2 and a == 1:
+                            spec = 1
+                        elif a == 0:
+                            raise AssertionError("lane 0 is never flagged")
+                        else:
+                            spec = 2  # the re-match probe of the last copy is the cut lane
+                    else:
+                        spec, s, qi = 0, seg_s, e + 1 - zl
+                    break
+                i, cnd, L = found
+                base, wide = p0 + i, False
+                if L == lm and base + L < n:
+                    wide, L = True, lcp(cnd, base, lm, n - base)
+                records.append((next_emit, base - next_emit, base - cnd, L))
+                ip = base + L
+                next_emit = ip
+                c = i + L
+                if ip >= ip_limit:
+                    fin = True
+                    break
+                if wide or c >= ulim:
+                    spec = 2
+                    break
+                insert(c - 1)
+                a, zl, lim, seg_s = c, c + 1, c + 32, ip + 1
+            for l in ins:
+                if l not in dead:
+                    tab[h[l]] = pos[l]
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
