@@ -817,6 +817,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				int i = m0 ? (int)first_lane(m0) : 64;
 				int last = -1;
 				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
+				uint32_t wide_len = 0;
 				if (i <= lim && i <= 63) {
 					for (;;) {
 						if ((special >> i) & 1) {
@@ -863,8 +864,22 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 								stop = last >= 0 ? 65u : 67u;
 								break;
 							}
-							stop = 66;
-							break;
+							/* a match longer than the lane-local cap: extend it wave-wide.  If it
+							 * still ends inside the usable lanes it is a link of the chain like
+							 * any other; else it ends the step. */
+							wide_len = kLocalMatch + extend(rdlane(cand, i), p0_c + (uint32_t)i);
+							if (PROF)
+								n_wide++;
+							if (i + (int)wide_len >= ulim) {
+								stop = 66;
+								break;
+							}
+							if ((int)lane == i)
+								mlen = wide_len;
+							cl = lane + mlen;
+							next_stop();
+							widemask &= ~(1ull << i);
+							special = widemask | flagmask;
 						}
 						taken |= 1ull << i;
 						last = i;
@@ -893,16 +908,14 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				}
 				uint32_t wbase_l = 0, wcnd = 0;
 				if (stop == 66) {
-					/* a match longer than the lane-local cap: extend it wave-wide; it ends the step */
+					/* the extended match runs past the usable lanes: it ends the step */
 					wbase_l = p0_c + (uint32_t)i;
 					wcnd = rdlane(cand, i);
-					const uint32_t L = kLocalMatch + extend(wcnd, wbase_l);
+					const uint32_t L = wide_len;
 					e_final = i;
 					ip = wbase_l + L;
-					if (PROF) {
+					if (PROF)
 						n_match++;
-						n_wide++;
-					}
 					spec = 2;
 					if (ip >= ip_limit)
 						fin = true;

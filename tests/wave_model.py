@@ -593,9 +593,11 @@ def compress_fragment_v4(F, p, s_entries=None, stats=None, lm=LM, fallback_cut=F
                 if ip >= ip_limit:
                     fin = True
                     break
-                if wide or c >= ulim:
+                if c >= ulim:
                     spec = 2
                     break
+                # (a match extended past the lane-local cap that still ends inside the usable lanes
+                # is a link of the chain like any other)
                 insert(c - 1)
                 a, zl, lim, seg_s = c, c + 1, c + 32, ip + 1
             for l in ins:

@@ -28,7 +28,7 @@ L.csnappy_hip_debug_set_profile_buffer(None)
 v = prof.cpu().tolist()
 nf = v[9]
 names = ["total", "vec", "walk", "commit", "publish"]
-print("table mode:", os.environ.get("CSNAPPY_HIP_TABLE", "lds"))
+print("table mode:", os.environ.get("CSNAPPY_HIP_TABLE", "auto (by LDS occupancy)"))
 print(f"fragments {nf}  steps/frag {v[5]/nf:.1f}  matches/frag {v[6]/nf:.1f}  wide/frag {v[7]/nf:.1f}  sparse/frag {v[8]/nf:.1f}")
 for i, n in enumerate(names):
     print(f"  {n:8s} {v[i]/nf:12.0f} ticks/frag   {v[i]/max(v[5],1):9.1f} per step   {v[i]/max(v[6],1):9.1f} per match")
