@@ -778,25 +778,20 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				 *      65 -> none of the 33 probes after my match (re-match + 32 scan) matches */
 				/* flagged lanes are stops of the chain like matches: what they hold is decided
 				 * when (and if) the chain gets there */
-				uint64_t flagmask = ulim < 64 ? cmask & ((1ull << ulim) - 1) : cmask;
+				const uint64_t flagmask = ulim < 64 ? cmask & ((1ull << ulim) - 1) : cmask;
 				const uint64_t stopmask = matchmask | flagmask;
-				uint32_t nx;
+				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
+				const uint64_t special = widemask | flagmask; /* stops that are not plain matches */
+				uint32_t nx; /* ... | 128 when that next stop is a special lane */
 				auto next_stop = [&]() {
 					const uint64_t rest = cl < 64 ? stopmask >> cl : 0;
 					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
 					const uint32_t j = cl + fm;
-					nx = (int)cl >= ulim ? 64u : (fm <= 32 && j <= 63) ? j : 65u;
+					const bool in = (fm <= 32 && j <= 63);
+					const uint32_t sp = in ? (uint32_t)(special >> j) & 1u : 0u;
+					nx = (int)cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
 				};
 				next_stop();
-				uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
-				uint64_t special = widemask | flagmask;
-				/* lanes strictly inside a copy of the chain so far (never probed, never inserted) */
-				auto inside_of = [&](uint64_t tk) -> bool {
-					const uint64_t below = tk & lt_mask;
-					const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-					return below != 0 && lane + 1 < cprev;
-				};
 				int a, zl;      /* first lane that may probe, lane of scan index 0 */
 				uint32_t seg_s; /* scan start of the current segment */
 				if (spec == 2) {
@@ -818,17 +813,34 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				int last = -1;
 				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
 				uint32_t wide_len = 0;
+				/* the same as next_stop() for one match on the scalar unit: c = lane behind it */
+				auto scalar_next = [&](int c) -> uint32_t {
+					if (c >= ulim)
+						return 64u;
+					const uint64_t rest = stopmask >> c;
+					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					const uint32_t j = (uint32_t)c + fm;
+					if (fm > 32 || j > 63)
+						return 65u;
+					return j | (((uint32_t)(special >> j) & 1u) << 7);
+				};
 				if (i <= lim && i <= 63) {
+					bool sp = (special >> i) & 1;
 					for (;;) {
-						if ((special >> i) & 1) {
+						uint32_t t;
+						if (sp) {
+							uint32_t L = kLocalMatch;
 							if ((flagmask >> i) & 1) {
 								/* ---- the chain probes a flagged lane ----
 								 * Its candidate is the latest position inserted for its slot: the
-								 * highest lane below it that this step inserts and that has the same
-								 * hash -- whose bytes are that lane's own 16 bytes -- else the table
-								 * value.  (Global placements did not gather the latter: cut here.) */
-								flagmask &= ~(1ull << i);
-								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(inside_of(taken));
+								 * highest lane below it that this step inserts (not strictly inside a
+								 * copy of the chain) and that has the same hash -- whose bytes are
+								 * that lane's own 16 bytes -- else the table value.  (Global
+								 * placements did not gather the latter: cut the step here.) */
+								const uint64_t below = taken & lt_mask;
+								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(below != 0 && lane + 1 < cprev);
 								const uint64_t same = __ballot(h == rdlane(h, i)) & ins;
 								if (same) {
 									const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
@@ -838,6 +850,7 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 									const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
 									const uint32_t ml = ylo ? (uint32_t)(__builtin_ctzll(ylo) >> 3)
 											: yhi ? 8u + (uint32_t)(__builtin_ctzll(yhi) >> 3) : 16u;
+									L = rdlane(ml, i);
 									if ((int)lane == i) {
 										cand = p0_c + j;
 										mlen = ml;
@@ -846,49 +859,64 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 									ulim = i;
 									stop = last < 0 ? 67u : (int)rdlane(cl, last) >= i ? 64u : 65u;
 									break;
+								} else {
+									L = rdlane(mlen, i);
 								}
-								cl = lane + mlen;
-								next_stop();
-								widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
-								special = widemask | flagmask;
-								if (rdlane(mlen, i) >= 4)
-									continue; /* a match: take it (or extend it) like any other */
-								/* no match: on to the next stop of the current segment */
-								const int lim_cur = last >= 0 ? (int)rdlane(cl, last) + 32 : lim;
-								const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
-								const int i2 = m ? (int)first_lane(m) : 64;
-								if (i2 <= lim_cur && i2 <= 63) {
+								if (L < 4) {
+									/* no match: on to the next stop of the current segment */
+									const int lim_cur = last >= 0 ? (int)rdlane(cl, last) + 32 : lim;
+									const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
+									const int i2 = m ? (int)first_lane(m) : 64;
+									if (i2 > lim_cur || i2 > 63) {
+										stop = last >= 0 ? 65u : 67u;
+										break;
+									}
 									i = i2;
+									sp = (special >> i) & 1;
 									continue;
 								}
-								stop = last >= 0 ? 65u : 67u;
-								break;
 							}
-							/* a match longer than the lane-local cap: extend it wave-wide.  If it
-							 * still ends inside the usable lanes it is a link of the chain like
-							 * any other; else it ends the step. */
-							wide_len = kLocalMatch + extend(rdlane(cand, i), p0_c + (uint32_t)i);
-							if (PROF)
-								n_wide++;
-							if (i + (int)wide_len >= ulim) {
-								stop = 66;
-								break;
+							if (L == kLocalMatch && p0_c + (uint32_t)i + kLocalMatch < n) {
+								/* a match longer than the lane-local cap: extend it wave-wide.  If it
+								 * still ends inside the usable lanes it is a link of the chain like
+								 * any other; else it ends the step. */
+								L = wide_len = kLocalMatch + extend(rdlane(cand, i), p0_c + (uint32_t)i);
+								if (PROF)
+									n_wide++;
+								if (i + (int)L >= ulim) {
+									stop = 66;
+									break;
+								}
 							}
-							if ((int)lane == i)
-								mlen = wide_len;
-							cl = lane + mlen;
-							next_stop();
-							widemask &= ~(1ull << i);
-							special = widemask | flagmask;
+							if ((int)lane == i) {
+								mlen = L;
+								cl = lane + L;
+							}
+							taken |= 1ull << i;
+							last = i;
+							t = scalar_next(i + (int)L);
+						} else {
+							/* plain matches: hop from match to match */
+							for (;;) {
+								taken |= 1ull << i;
+								last = i;
+								t = rdlane(nx, i);
+								if (t >= 64)
+									break;
+								i = (int)t;
+							}
 						}
-						taken |= 1ull << i;
-						last = i;
-						const uint32_t t = rdlane(nx, i);
-						if (t >= 64) {
-							stop = t;
+						if (t < 64) {
+							i = (int)t;
+							sp = false;
+							continue;
+						}
+						if (t < 128) {
+							stop = t; /* 64 / 65 */
 							break;
 						}
-						i = (int)t;
+						i = (int)(t & 63);
+						sp = true;
 					}
 				}
 				if (PROF) {
