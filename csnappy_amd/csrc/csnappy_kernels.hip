@@ -1166,32 +1166,58 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stitch_blocks(CompressA
  *      other with the whole wave, dst[j] = dst[j mod offset - offset]  (:188-206 semantics).
  * ======================================================================================== */
 
-/* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment */
+/* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment: the pieces
+ * 16,16,16,16 / 8 / 4 / 2 / 1 that make up len are all loaded first (one memory round trip for
+ * the lane, whatever its length), then all stored */
 DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
 {
-	uint32_t k = 0;
-	while (__ballot(active && k + 8 <= len)) {
-		if (active && k + 8 <= len) {
-			uint64_t v;
-			__builtin_memcpy(&v, s + k, 8);
-			__builtin_memcpy(d + k, &v, 8);
-			k += 8;
+	const uint32_t n16 = active ? len >> 4 : 0; /* 0..4 */
+	const uint32_t o8 = len & ~15u, o4 = len & ~7u, o2 = len & ~3u, o1 = len & ~1u;
+	const bool b8 = active && (len & 8), b4 = active && (len & 4);
+	const bool b2 = active && (len & 2), b1 = active && (len & 1);
+	uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+	uint64_t p8 = 0;
+	uint32_t p4 = 0;
+	uint16_t p2 = 0;
+	uint8_t p1 = 0;
+	if (n16 > 0) {
+		__builtin_memcpy(&c0, s, 16);
+		if (n16 > 1) {
+			__builtin_memcpy(&c1, s + 16, 16);
+			if (n16 > 2) {
+				__builtin_memcpy(&c2, s + 32, 16);
+				if (n16 > 3)
+					__builtin_memcpy(&c3, s + 48, 16);
+			}
 		}
 	}
-	if (active && len - k >= 4) {
-		uint32_t v;
-		__builtin_memcpy(&v, s + k, 4);
-		__builtin_memcpy(d + k, &v, 4);
-		k += 4;
+	if (b8)
+		__builtin_memcpy(&p8, s + o8, 8);
+	if (b4)
+		__builtin_memcpy(&p4, s + o4, 4);
+	if (b2)
+		__builtin_memcpy(&p2, s + o2, 2);
+	if (b1)
+		p1 = s[o1];
+	if (n16 > 0) {
+		__builtin_memcpy(d, &c0, 16);
+		if (n16 > 1) {
+			__builtin_memcpy(d + 16, &c1, 16);
+			if (n16 > 2) {
+				__builtin_memcpy(d + 32, &c2, 16);
+				if (n16 > 3)
+					__builtin_memcpy(d + 48, &c3, 16);
+			}
+		}
 	}
-	if (active && len - k >= 2) {
-		uint16_t v;
-		__builtin_memcpy(&v, s + k, 2);
-		__builtin_memcpy(d + k, &v, 2);
-		k += 2;
-	}
-	if (active && len - k >= 1)
-		d[k] = s[k];
+	if (b8)
+		__builtin_memcpy(d + o8, &p8, 8);
+	if (b4)
+		__builtin_memcpy(d + o4, &p4, 4);
+	if (b2)
+		__builtin_memcpy(d + o2, &p2, 2);
+	if (b1)
+		d[o1] = p1;
 }
 
 extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(DecompressArgs A)
@@ -1254,22 +1280,17 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				if (at + 1 + k < n)
 					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
 		}
+		/* (selects, not branches: the bytes that are not tags decode to every kind) */
 		const uint32_t kind = b0 & 3;
-		uint32_t l, extra, off = 0;
-		if (kind == 0) {
-			l = (b0 >> 2) + 1;
-			extra = l > 60 ? l - 60 : 0;
-			if (extra)
-				l = (extra == 4 ? tr : (tr & ((1u << (8 * extra)) - 1))) + 1;
-		} else if (kind == 1) {
-			l = 4 + ((b0 >> 2) & 7);
-			extra = 1;
-			off = ((b0 >> 5) << 8) | (tr & 0xff);
-		} else {
-			l = (b0 >> 2) + 1;
-			extra = kind == 2 ? 2 : 4;
-			off = kind == 2 ? (tr & 0xffff) : tr;
-		}
+		const uint32_t up = b0 >> 2;
+		const uint32_t lx = up >= 60 ? up - 59 : 0; /* literal: extra length bytes, :351-353 */
+		const uint32_t lbig = __builtin_amdgcn_ubfe(tr, 0, 8 * lx) + 1; /* width 0 reads as 0 */
+		const uint32_t l = kind == 0 ? (lx ? (lx == 4 ? tr + 1 : lbig) : up + 1)
+				 : kind == 1 ? 4 + (up & 7) : up + 1;
+		const uint32_t extra = kind == 0 ? lx : kind == 3 ? 4u : kind;
+		const uint32_t off = kind == 0 ? 0u
+				   : kind == 1 ? ((b0 >> 5) << 8) | (tr & 0xff)
+				   : kind == 2 ? (tr & 0xffff) : tr;
 		const uint32_t hsz = 1 + extra;
 		/* bytes this element takes in the input (a literal length that would wrap 32 bits is
 		 * negative as int32 and fails below whatever the walk does after it) */
@@ -1279,11 +1300,12 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		uint64_t tmask = 0;
 		uint32_t cur = 0;
 		const uint32_t room = n - ip; /* > 0 */
-		while (cur < 64 && cur < room) {
+		const uint32_t wlim = min(64u, room);
+		const uint32_t nxt = lane + esz < lane ? 0xffffffffu : lane + esz; /* next tag if I am one */
+		do {
 			tmask |= 1ull << cur;
-			const uint32_t e = rdlane(esz, cur);
-			cur = cur + e < cur ? 0xffffffffu : cur + e; /* saturating */
-		}
+			cur = rdlane(nxt, cur);
+		} while (cur < wlim);
 		const bool istag = (tmask >> lane) & 1;
 		/* request the next iteration's bytes now; they arrive while this one's copies run */
 		have_next = cur < room && room - cur >= 64 + 8;
