@@ -1175,11 +1175,13 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
 	const uint32_t o8 = len & ~15u, o4 = len & ~7u, o2 = len & ~3u, o1 = len & ~1u;
 	const bool b8 = active && (len & 8), b4 = active && (len & 4);
 	const bool b2 = active && (len & 2), b1 = active && (len & 1);
-	uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
-	uint64_t p8 = 0;
-	uint32_t p4 = 0;
-	uint16_t p2 = 0;
-	uint8_t p1 = 0;
+	/* (deliberately not initialised: each piece is stored under the condition it was loaded
+	 * under, and initialisers would cost 21 moves per call) */
+	uint4 c0, c1, c2, c3;
+	uint64_t p8;
+	uint32_t p4;
+	uint16_t p2;
+	uint8_t p1;
 	if (n16 > 0) {
 		__builtin_memcpy(&c0, s, 16);
 		if (n16 > 1) {
@@ -1280,17 +1282,19 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				if (at + 1 + k < n)
 					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
 		}
-		/* (selects, not branches: the bytes that are not tags decode to every kind) */
+		/* (flat arithmetic and selects, no branches: the bytes that are not tags decode to every
+		 * kind, so every branch would be taken by some lane anyway) */
 		const uint32_t kind = b0 & 3;
 		const uint32_t up = b0 >> 2;
-		const uint32_t lx = up >= 60 ? up - 59 : 0; /* literal: extra length bytes, :351-353 */
-		const uint32_t lbig = __builtin_amdgcn_ubfe(tr, 0, 8 * lx) + 1; /* width 0 reads as 0 */
-		const uint32_t l = kind == 0 ? (lx ? (lx == 4 ? tr + 1 : lbig) : up + 1)
-				 : kind == 1 ? 4 + (up & 7) : up + 1;
-		const uint32_t extra = kind == 0 ? lx : kind == 3 ? 4u : kind;
-		const uint32_t off = kind == 0 ? 0u
-				   : kind == 1 ? ((b0 >> 5) << 8) | (tr & 0xff)
-				   : kind == 2 ? (tr & 0xffff) : tr;
+		const bool is_lit = kind == 0, is_c1 = kind == 1;
+		const uint32_t lx = max(up, 59u) - 59u;               /* literal: extra length bytes 0..4, :351-353 */
+		const uint32_t cx = kind + ((kind >> 1) & kind);       /* copy: offset bytes 1, 2, 4 */
+		const uint32_t extra = is_lit ? lx : cx;
+		const uint32_t xmask = 0xffffffffu >> ((32u - 8u * extra) & 31u); /* extra 0 -> all ones (unused) */
+		const uint32_t trm = tr & xmask;
+		const uint32_t l_short = is_c1 ? 4 + (up & 7) : up + 1;
+		const uint32_t l = (is_lit && lx != 0) ? trm + 1 : l_short;
+		const uint32_t off = is_lit ? 0u : trm | (is_c1 ? (b0 >> 5) << 8 : 0u);
 		const uint32_t hsz = 1 + extra;
 		/* bytes this element takes in the input (a literal length that would wrap 32 bits is
 		 * negative as int32 and fails below whatever the walk does after it) */
@@ -1321,21 +1325,15 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const uint32_t eff = (istag && !inbad) ? l : 0;
 		const uint32_t excl = wave_incl_scan_dpp(eff) - eff;
 		const uint32_t pb = op + excl; /* bytes produced before this element */
-		int32_t err = 0;
-		if (istag) {
-			const bool overrun = limit - pb < l;
-			if (trunc)
-				err = CSNAPPY_E_DATA_MALFORMED;
-			else if (kind == 0)
-				err = lit_short ? CSNAPPY_E_DATA_MALFORMED
-				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN /* :288-289, :274-275 */
-				      : lit_neg ? CSNAPPY_E_DATA_MALFORMED
-						: 0;
-			else
-				err = (off == 0 || off > pb) ? CSNAPPY_E_DATA_MALFORMED /* :301-303 */
-				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN	     /* :311-312 */
-						: 0;
-		}
+		/* literal: short input (-5), then output overrun (-3, :288-289, :274-275), then a length
+		 * that is negative as int32 (-5); copy: offset 0 or beyond what was produced (-5,
+		 * :301-303), then output overrun (-3, :311-312); cut-off header bytes first of all (-5) */
+		const bool overrun = limit - pb < l;
+		const bool first5 = trunc || (is_lit ? lit_short : (off == 0 || off > pb));
+		const int32_t err_tag = first5 ? CSNAPPY_E_DATA_MALFORMED
+				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN
+				      : lit_neg ? CSNAPPY_E_DATA_MALFORMED : 0;
+		const int32_t err = istag ? err_tag : 0;
 		const uint64_t emask = __ballot(err != 0);
 		const uint32_t fe = emask ? first_lane(emask) : 64;
 		const uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask; /* elements to execute */
