@@ -97,12 +97,19 @@ def cpu_baseline(kind, seed, block, p, mode, nblocks_avail, target_s, urls=None)
         tc += a
         td += b_
     gib = nb * block * reps / 2.0 ** 30
+    # the same path on ONE thread as well (a ~2 s sample)
+    nb1 = int(max(16, min(nb, 2.0 / max(per_block * cores, 1e-9))))
+    run(nb1, 1)
+    c1, d1 = run(nb1, 1)
+    gib1 = nb1 * block / 2.0 ** 30
     return {
         "value": round(gib / (tc + td), 4), "unit": "GiB/s", "cores": cores, "kind": codec.kind,
         "sample": f"first {nb} blocks x {block} B of the same workload, {reps} repetition(s) "
                   f"({gib:.3f} GiB in total): compress {tc:.2f} s + decompress {td:.2f} s on {cores} "
                   "threads (one block range per thread)",
         "compress_gibs": round(gib / tc, 4), "decompress_gibs": round(gib / td, 4),
+        "one_thread": {"value": round(gib1 / (c1 + d1), 4), "compress_gibs": round(gib1 / c1, 4),
+                       "decompress_gibs": round(gib1 / d1, 4), "sample": f"first {nb1} blocks, 1 thread"},
     }
 
 
