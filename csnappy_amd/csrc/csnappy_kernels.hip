@@ -1486,6 +1486,15 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
 size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries, uint32_t *s_shift)
 {
 	uint32_t s_cap = placement ? 512u : 1024u; /* global placements: two 512-entry filters */
+	if (placement == 0) {
+		/* LDS placement: a false alarm of the filter only costs a visit of the flagged lane, one
+		 * more fragment per CU is worth more (4 KiB pages at p=13: 7 -> 8 per CU, +4 %) */
+		const size_t rest = (size_t)win_bytes + ((size_t)1 << p) + kRingBytes + kStageBytes;
+		const uint32_t full = (1u << (p - 1)) < 1024u ? (1u << (p - 1)) : 1024u;
+		const uint32_t half = full > 512u ? 512u : full;
+		if (kLdsPerCu / (rest + half * 4) > kLdsPerCu / (rest + full * 4))
+			s_cap = 512u;
+	}
 	if (const char *e = getenv("CSNAPPY_HIP_S_ENTRIES")) /* experiments */
 		s_cap = (uint32_t)atoi(e);
 	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
