@@ -1169,7 +1169,7 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stitch_blocks(CompressA
 /* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment: the pieces
  * 16,16,16,16 / 8 / 4 / 2 / 1 that make up len are all loaded first (one memory round trip for
  * the lane, whatever its length), then all stored */
-DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
+DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, uint64_t &carried)
 {
 	const uint32_t n16 = active ? len >> 4 : 0; /* 0..4 */
 	const uint32_t o8 = len & ~15u, o4 = len & ~7u, o2 = len & ~3u, o1 = len & ~1u;
@@ -1201,6 +1201,11 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active)
 		__builtin_memcpy(&p2, s + o2, 2);
 	if (b1)
 		p1 = s[o1];
+	/* `carried` is a load issued before this call whose value is needed only in the next loop
+	 * iteration.  Using it here makes the compiler wait for it now, together with the loads
+	 * above; otherwise it waits at the loop top with vmcnt(0) -- gfx9 has one counter for loads
+	 * and stores -- and every iteration would sit out the round trip of the stores below. */
+	asm volatile("" : "+v"(carried));
 	if (n16 > 0) {
 		__builtin_memcpy(d, &c0, 16);
 		if (n16 > 1) {
@@ -1347,7 +1352,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const bool lit = exec_me && kind == 0;
 		const bool cpy = exec_me && kind != 0;
 		const bool indep = cpy && off >= excl + l;
-		copy_exact(edst, lit ? lsrc : edst - off, l, (lit && l <= 64) || indep);
+		copy_exact(edst, lit ? lsrc : edst - off, l, (lit && l <= 64) || indep, next8);
 		for (uint64_t big = __ballot(lit && l > 64); big; big &= big - 1) {
 			const uint32_t t = first_lane(big);
 			const uint32_t L = rdlane(l, t);
