@@ -1279,6 +1279,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			__builtin_memcpy(&v, src + at, 8);
 			b0 = (uint32_t)v & 0xff;
 			tr = (uint32_t)(v >> 8);
+			asm volatile("" : "+v"(b0), "+v"(tr)); /* wait here, not where the paths join */
 		} else {
 			if (at < n)
 				b0 = src[at];
@@ -1286,6 +1287,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			for (int k = 0; k < 4; ++k)
 				if (at + 1 + k < n)
 					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
+			asm volatile("" : "+v"(b0), "+v"(tr));
 		}
 		/* (flat arithmetic and selects, no branches: the bytes that are not tags decode to every
 		 * kind, so every branch would be taken by some lane anyway) */
