@@ -1019,6 +1019,12 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			/* commit table[hash] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
+			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
+			 * of the table stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
+			 * behind the stores (at the loop's back edge, where the compiler would put it) also sits
+			 * out the stores' round trip -- once per step, on the dependent chain. */
+			if (GWIN)
+				asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
 			bool commit = (int)lane <= e_final && !inside;
 			{
 				/* of several committed lanes with one slot only the last may write (flagged lanes
