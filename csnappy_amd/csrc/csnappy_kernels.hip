@@ -1366,12 +1366,20 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			const uint32_t L = rdlane(l, t);
 			const uint8_t *ps = src + (ip + t + rdlane(hsz, t));
 			uint8_t *pd = dst + (op + rdlane(excl, t));
-			/* long literal: 16 B per lane per iteration (unaligned vector accesses), byte tail */
+			/* long literal: 4 x 16 B per lane per iteration (unaligned vector accesses; the four
+			 * loads are issued before the first store so that one round trip moves 4 KiB), byte
+			 * tail */
 			const uint32_t body = L & ~15u;
-			for (uint32_t j = lane * 16; j < body; j += 1024) {
-				uint4 v;
-				__builtin_memcpy(&v, ps + j, 16);
-				__builtin_memcpy(pd + j, &v, 16);
+			for (uint32_t j0 = lane * 16; j0 < body; j0 += 4096) {
+				uint4 v[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					if (j0 + 1024u * k < body)
+						__builtin_memcpy(&v[k], ps + j0 + 1024u * k, 16);
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					if (j0 + 1024u * k < body)
+						__builtin_memcpy(pd + j0 + 1024u * k, &v[k], 16);
 			}
 			if (body + lane < L)
 				pd[body + lane] = ps[body + lane];
