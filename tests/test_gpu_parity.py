@@ -6,6 +6,7 @@ import gzip
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -564,3 +565,41 @@ def test_rccl_gather_of_the_compacted_stream_single_rank(torch, urls):
         assert sha(b"".join(blocks)) == GOLD["urls_blocks"]["64k_p16"]["sha256"]
     finally:
         dist.destroy_process_group()
+
+
+# -------------------------------------------------------------------------------------------------
+# the driver's entry points: smoke() and the bench line
+# -------------------------------------------------------------------------------------------------
+def test_graft_entry_smoke(torch):
+    import importlib
+    sys.path.insert(0, os.path.dirname(HERE))
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(torch):
+    """bench.py on a small batch: one JSON line, the contract's keys, roofline and cpu_baseline
+    objects, kernel times that add up to the step."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gib", "0.0625", "--steps", "2",
+                        "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600,
+                       cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "GiB/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["value"] > 0
+    kt = sum(v["ms_per_step"] for v in d["kernels"].values())
+    assert 0.5 * d["ms_per_step"] <= kt <= 1.05 * d["ms_per_step"], (kt, d["ms_per_step"])
