@@ -17,9 +17,10 @@
  *   - compress: one workgroup of two waves per 32 KiB fragment.  The PARSER wave reproduces the
  *     reference's sequential probe loop exactly, 64 consecutive positions per step: every lane
  *     hashes its 4 bytes, gathers table[h], measures a lane-local match length against its
- *     candidate; the step is cut at the first lane that shares a hash slot with an earlier lane
- *     (the only way a lane's table read could be stale), and the chain of copies through the
- *     step is followed on the scalar unit.  The EMITTER wave encodes the queued (literal, copy)
+ *     candidate; a lane that shares a hash slot with an earlier lane of the step (the only way
+ *     its table read could be stale) is flagged and resolved from that lane's registers if the
+ *     chain of copies -- followed on the scalar unit, six instructions per copy -- ever probes
+ *     it.  The EMITTER wave encodes the queued (literal, copy)
  *     records and writes them out with aligned 16 B/lane stores.  The hash table and the window
  *     live in LDS when at least four fragments fit a CU that way, else in global memory.
  *   - decompress: one wave per block; 64 candidate tag positions are decoded in parallel, the
