@@ -89,13 +89,14 @@ def cpu_baseline(kind, seed, block, p, mode, nblocks_avail, target_s, urls=None)
     per_block = (tc + td) / probe
     nb = int(min(nblocks_avail, max(probe, target_s / per_block)))
     nb = min(nb, (4 << 30) // block)  # bound host memory
-    # repeat the sample until ~target_s of CPU work has been timed
-    reps = int(max(1, min(64, target_s / max(per_block * nb, 1e-6))))
-    tc = td = 0.0
-    for _ in range(reps):
+    # repeat the sample until ~target_s of wall time has been timed (the probe above is cold --
+    # thread start-up, page faults -- so the repetition count is decided on the clock, not on it)
+    reps, tc, td = 0, 0.0, 0.0
+    while reps < 1 or (tc + td < target_s and reps < 400):
         a, b_ = run(nb, cores)
         tc += a
         td += b_
+        reps += 1
     gib = nb * block * reps / 2.0 ** 30
     # the same path on ONE thread as well (a ~2 s sample)
     nb1 = int(max(16, min(nb, 2.0 / max(per_block * cores, 1e-9))))
