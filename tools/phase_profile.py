@@ -9,11 +9,17 @@ import torch
 from csnappy_amd import api
 
 kind, seed, block, p, mode = {"text": (0, 0xC5A90001, 65536, 16, 0), "low": (1, 0xC5A90005, 65536, 16, 0),
-                              "page": (2, 0xC5A90004, 4096, 13, 1)}[sys.argv[1] if len(sys.argv) > 1 else "text"]
+                              "page": (2, 0xC5A90004, 4096, 13, 1), "urls": (-1, 0, 65536, 16, 0)}[sys.argv[1] if len(sys.argv) > 1 else "text"]
 if len(sys.argv) > 2:
     p = int(sys.argv[2])
 nb = (256 << 20) // block
-d_in = api.generate(kind, seed, 0, nb, block)
+if kind >= 0:
+    d_in = api.generate(kind, seed, 0, nb, block)
+else:
+    import numpy as np
+    raw = np.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "urls.10K"),
+                      dtype=np.uint8)
+    d_in = torch.from_numpy(np.resize(raw, nb * block)).cuda()
 b = api.Batch([block] * nb)
 d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
 prof = torch.zeros(16, dtype=torch.int64, device="cuda")
