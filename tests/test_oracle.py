@@ -195,13 +195,10 @@ def test_port_equals_compiled_reference_on_corrupted_streams():
     assert checked > 500
 
 
-def _has_truncated_tag(stream):
-    """True if walking the tags hits a tag whose extra bytes run past the end of input."""
-    P = oracle.Port()
-    rc, _ = P.get_uncompressed_length(stream)
-    if rc < 0:
-        return False
-    i, n = rc, len(stream)
+def _body_has_truncated_tag(stream, i=0):
+    """True if walking the tags from offset i hits a tag whose extra bytes run past the end of
+    input (the reference then reads stale stack bytes: undefined)."""
+    n = len(stream)
     while i < n:
         t = stream[i]
         k = t & 3
@@ -211,7 +208,7 @@ def _has_truncated_tag(stream):
             if i + 1 + ex > n:
                 return True
             if ex:
-                ln = int.from_bytes(stream[i + 1:i + 1 + ex], "little") + 1
+                ln = (int.from_bytes(stream[i + 1:i + 1 + ex], "little") + 1) & 0xffffffff  # uint32, as the reference
             i += 1 + ex + ln
         else:
             ex = (1, 2, 4)[k - 1]
@@ -219,6 +216,12 @@ def _has_truncated_tag(stream):
                 return True
             i += 1 + ex
     return False
+
+
+def _has_truncated_tag(stream):
+    """The same for a stream with its varint header (False if the header itself is bad)."""
+    rc, _ = oracle.Port().get_uncompressed_length(stream)
+    return rc >= 0 and _body_has_truncated_tag(stream, rc)
 
 
 # ---- the wave-step algorithm of the HIP compress kernel ---------------------------------------
