@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one batch that is already resident in HBM:
-compress every block of the batch (snappy_compress_fragments + snappy_stitch_blocks), then
+compress every block of the batch (snappy_parse_fragments + snappy_emit_blocks), then
 decompress every block back (snappy_decompress_blocks).  The default workload is BASELINE.json
 configs[1]: 1 GiB of the G_text synthetic per GPU, cut into 65536-byte blocks, STREAM mode
 (csnappy_compress / csnappy_decompress semantics), table power 16.  Blocks are independent, so
@@ -47,7 +47,7 @@ def load_measured_traffic(workload, p):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        return t.get(f"{workload}_p{p}", {}).get("snappy_compress_fragments_bytes_per_batch")
+        return t.get(f"{workload}_p{p}", {}).get("snappy_parse_fragments_bytes_per_batch")
     except (OSError, ValueError):
         return None
 
@@ -239,15 +239,15 @@ def main():
 
     # ---- roofline of the dominant kernel (this GPU) ----------------------------------------------
     # algorithmic bytes per launch: compress N_in + C_out, decompress C_in + N_out
-    alg = {"snappy_compress_fragments": n_bytes + comp_bytes,
-           "snappy_stitch_blocks": comp_bytes,  # <= half of C is moved (read + write)
+    alg = {"snappy_parse_fragments": n_bytes + comp_bytes,
+           "snappy_emit_blocks": comp_bytes,  # records in, literal bytes in, C out
            "snappy_decompress_blocks": comp_bytes + n_bytes}
-    dom = max(("snappy_compress_fragments", "snappy_decompress_blocks"),
+    dom = max(("snappy_parse_fragments", "snappy_decompress_blocks"),
               key=lambda k: kernels[k]["ms_per_step"])
     nch = len(chunks)
     dom_s = kernels[dom]["ms_per_step"] / 1e3
     achieved = alg[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
-    traffic = load_measured_traffic(args.workload, p) if (dom == "snappy_compress_fragments" and nch == 1
+    traffic = load_measured_traffic(args.workload, p) if (dom == "snappy_parse_fragments" and nch == 1
                                                           and args.gib == 1.0 and args.block is None) else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -272,8 +272,8 @@ def main():
                    "chunks_per_step": len(chunks),
                    "sharding": f"block ranges, {world} rank(s), no data-path collective"},
         "compressed_ratio": round(comp_bytes / n_bytes, 6),
-        "compress_gibs": gibs(kernels["snappy_compress_fragments"]["ms_per_step"]
-                              + kernels["snappy_stitch_blocks"]["ms_per_step"]),
+        "compress_gibs": gibs(kernels["snappy_parse_fragments"]["ms_per_step"]
+                              + kernels["snappy_emit_blocks"]["ms_per_step"]),
         "decompress_gibs": gibs(kernels["snappy_decompress_blocks"]["ms_per_step"]),
         "kernels": kernels,
         "roofline": roofline,

@@ -208,7 +208,7 @@ def get_kernel_timing():
     """-> {kernel: (total_ms, launches)} since the previous read (waits for the events)."""
     ms, cnt = (C.c_float * 4)(), (C.c_uint32 * 4)()
     lib().csnappy_hip_get_kernel_timing(ms, cnt)
-    names = ("snappy_compress_fragments", "snappy_stitch_blocks", "snappy_decompress_blocks")
+    names = ("snappy_parse_fragments", "snappy_emit_blocks", "snappy_decompress_blocks")
     return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
 

@@ -45,7 +45,6 @@ namespace {
 constexpr uint32_t kFragment = 32768;    /* kBlockSize, csnappy_compress.c:85-86 */
 constexpr uint32_t kMargin = 15;         /* kInputMarginBytes, csnappy_compress.c:468 */
 constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
-constexpr uint32_t kScratchSlot = 38400; /* >= max_compressed_length(32768)=38261, 256-aligned */
 
 #define DEVINL __device__ __forceinline__
 
@@ -56,19 +55,21 @@ struct CompressArgs {
 	uint8_t *out;
 	const uint64_t *out_off;
 	uint32_t *out_len;
-	uint8_t *scratch;   /* (fpb-1) slots of kScratchSlot bytes per block */
-	uint32_t *frag_len; /* fpb entries per block */
-	uint32_t nblocks;
+	uint64_t *recs;     /* rec_cap 8-byte records per fragment of the chunk */
+	uint32_t *rec_cnt;  /* records of each fragment of the chunk (kNoRecords: not parsed yet) */
+	uint8_t *tabs;      /* tab_stride bytes per fragment: dense ids, or the global-memory table */
+	unsigned long long *prof; /* debug cycle counters (PROF instantiations only) */
+	uint32_t blk_base;  /* first block of this chunk */
 	uint32_t fpb;       /* fragments per block (upper bound) */
-	uint32_t win_bytes; /* LDS bytes reserved for the window */
-	uint32_t s_entries; /* conflict-scratch entries per filter (power of two) */
-	uint32_t s_shift;   /* second filter's key = (h >> s_shift) & (s_entries - 1); 0 = one filter only */
+	uint32_t rec_cap;
+	uint32_t tab_stride;
+	uint32_t lds0;      /* LDS bytes in front of the conflict filters (table / occupancy bitmap) */
+	uint32_t dense_cap; /* entries of the dense LDS table */
+	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
+	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
+	uint32_t only_unparsed; /* TAB_GLOBAL: skip fragments that already have records */
 	int p;
 	int mode;
-	unsigned long long *prof; /* debug cycle counters (PROF instantiation only) */
-	uint16_t *gtab;   /* GTAB instantiation: one 2^p-byte hash table per workgroup of the launch */
-	uint32_t id_base; /* first fragment id of this launch (launches are chunked in GTAB mode) */
-	uint32_t width;   /* lanes that take a position per dense step (experiments; 64) */
 };
 
 struct DecompressArgs {
@@ -92,44 +93,6 @@ DEVINL uint32_t rdlane(uint32_t v, uint32_t l)
 DEVINL uint32_t first_lane(uint64_t m)
 {
 	return (uint32_t)__builtin_ctzll(m);
-}
-
-/* 4 bytes at an arbitrary byte index of an LDS array that is addressed as dwords. */
-DEVINL uint32_t lds_rd32(const uint32_t *w, uint32_t byte)
-{
-	const uint32_t d = byte >> 2;
-	return __builtin_amdgcn_alignbyte(w[d + 1], w[d], byte & 3);
-}
-
-DEVINL uint64_t lds_rd64(const uint32_t *w, uint32_t byte)
-{
-	const uint32_t d = byte >> 2, sh = byte & 3;
-	const uint32_t a = w[d], b = w[d + 1], c = w[d + 2];
-	const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sh);
-	const uint32_t hi = __builtin_amdgcn_alignbyte(c, b, sh);
-	return ((uint64_t)hi << 32) | lo;
-}
-
-/* Window readers.  G = the window is the input itself in global memory (unaligned vector loads);
- * otherwise it is the LDS copy (aligned dwords + v_alignbyte). */
-template <bool G> DEVINL uint32_t win_rd32(const uint32_t *w, uint32_t byte)
-{
-	if (G) {
-		uint32_t v;
-		__builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(w) + byte, 4);
-		return v;
-	}
-	return lds_rd32(w, byte);
-}
-
-template <bool G> DEVINL uint64_t win_rd64(const uint32_t *w, uint32_t byte)
-{
-	if (G) {
-		uint64_t v;
-		__builtin_memcpy(&v, reinterpret_cast<const uint8_t *>(w) + byte, 8);
-		return v;
-	}
-	return lds_rd64(w, byte);
 }
 
 /* inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS) */
@@ -213,23 +176,36 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 }
 
 /* ==========================================================================================
- * COMPRESS: one workgroup (2 waves) per fragment: wave 0 parses, wave 1 emits
+ * COMPRESS, kernel 1 of 2: snappy_parse_fragments -- ONE wave per 32 KiB fragment
  *
- * The parser's dependent chain (LDS round trips + single-wave instruction issue) is what bounds
- * the kernel, so everything that is not on that chain runs on another SIMD: the parser only
- * queues (literal, copy) records into an LDS ring; the emitter wave encodes them
- * (EmitLiteral/EmitCopy), stages the bytes in LDS and flushes them to HBM with aligned 16 B/lane
- * stores.  The two waves meet at one s_barrier per 64 records (double-buffered ring).
+ * The wave reproduces the reference's sequential probe loop exactly (csnappy_compress.c:469-606)
+ * and writes what it decided as 8-byte (literal, copy) records to HBM; snappy_emit_blocks turns
+ * the records into bytes.  The parser is one dependent chain per fragment, so throughput is
+ * (fragments in flight per CU) / (latency of a step): everything here is about keeping the
+ * per-fragment LDS footprint and the step short.
  *
- * Step logic (restated lane by lane in tests/wave_model.py::compress_fragment_v2 and fuzzed
+ * Hash table.  The reference's table has 2^(p-1) uint16 slots (64 KiB at p=16), far more than
+ * a fragment can use: a slot matters only if at least two positions of the fragment hash to it
+ * (a lone position can neither find a candidate nor be found).  A prologue therefore numbers
+ * the slots that are hit twice or more (two LDS bitmaps filled with atomicOr, a popcount
+ * prefix) and writes every position's dense bucket id to HBM; the table the parser then keeps in
+ * LDS has one uint16 entry per such bucket (~4.6 k on URL-like text, ~1 k on runs) and is indexed
+ * by the id, which the lanes load with their 16 input bytes.  Same slots, same contents, same
+ * order of updates as the reference's table -- only the slots nobody can ever read are gone.
+ * Fragments with more buckets than the LDS carve holds are handed to a second launch that keeps
+ * the full 2^p-byte table in global memory (TAB_GLOBAL); tables of <= 8 KiB are simply indexed
+ * by the hash (TAB_LDS_HASH, no prologue).  The window is never staged: the input is read where
+ * it lies.
+ *
+ * Step logic (restated lane by lane in tests/wave_model.py::compress_fragment_v4 and fuzzed
  * against the CPU checker):
  *   dense step   the 64 lanes take 64 CONSECUTIVE positions starting at the cursor.  Every lane
- *                hashes its 4 bytes, gathers table[h], and computes a lane-local match length
- *                (up to kLocalMatch bytes) against its candidate.  The step is truncated at the
- *                first lane that shares a hash slot with an earlier lane (exactness, see
- *                DESIGN.md 4.1).  The chain of matches through the step -- match at lane i of
+ *                looks its slot up and computes a lane-local match length (up to kLocalMatch
+ *                bytes) against its candidate.  A lane that shares its slot with an earlier
+ *                lane of the step is flagged and resolved from that lane's registers if the chain
+ *                gets there.  The chain of matches through the step -- match at lane i of
  *                length L, insert lane i+L-1, re-match probe at lane i+L, 32 stride-1 scan probes
- *                after it (csnappy_compress.c:535-598) -- is then walked on the scalar unit, so
+ *                after it (csnappy_compress.c:535-598) -- is walked on the scalar unit, so
  *                one step usually retires several copies.
  *   sparse step  once a scan has made 32 probes without a match the reference strides by 2, 3..
  *                (:542); lanes then take the next 64 probe positions of that stride rule and a
@@ -237,20 +213,11 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  * ======================================================================================== */
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
 constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging */
-constexpr uint32_t kFlushAt = 512;   /* staged bytes that trigger a coalesced flush */
-constexpr uint32_t kStageBytes = 16 + kFlushAt + 64 * kBigRecord + 16; /* LDS output staging */
-constexpr uint32_t kRingBytes = 2 * 64 * 16 + 16; /* two batches of 64 records (4 dwords each) + two count words */
+constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
+constexpr uint32_t kNoRecords = 0xffffffffu; /* rec_cnt: "not parsed yet, needs the global-table parser" */
+constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
 
-/* 16 bytes at an arbitrary byte index of LDS as four little-endian dwords */
-DEVINL void lds_rd128(const uint32_t *w, uint32_t byte, uint32_t out[4])
-{
-	const uint32_t d = byte >> 2, sh = byte & 3;
-	const uint32_t a = w[d], b = w[d + 1], c = w[d + 2], e = w[d + 3], f = w[d + 4];
-	out[0] = __builtin_amdgcn_alignbyte(b, a, sh);
-	out[1] = __builtin_amdgcn_alignbyte(c, b, sh);
-	out[2] = __builtin_amdgcn_alignbyte(e, c, sh);
-	out[3] = __builtin_amdgcn_alignbyte(f, e, sh);
-}
+enum { TAB_LDS_HASH = 0, TAB_LDS_DENSE = 1, TAB_GLOBAL = 2 };
 
 /* Orders this wave's LDS accesses for the compiler.  The LDS pipeline executes one wave's
  * instructions in issue order, so cross-lane exchange inside a wave needs no hardware wait. */
@@ -260,298 +227,187 @@ DEVINL void wave_lds_fence()
 	__builtin_amdgcn_wave_barrier();
 }
 
-template <bool PROF, bool GTAB, bool GWIN>
-__device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
+/* record: x = base | cand << 16, y = copy_len | lit_start << 16 (every field <= 32768) */
+DEVINL uint2 pack_record(uint32_t lit_start, uint32_t base, uint32_t cnd, uint32_t clen)
 {
+	return make_uint2(base | (cnd << 16), clen | (lit_start << 16));
+}
+
+template <bool PROF, int TAB>
+__device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
+{
+	constexpr bool GTAB = TAB == TAB_GLOBAL, DENSE = TAB == TAB_LDS_DENSE;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t lane = tid & 63;
-	const uint32_t role = tid >> 6; /* 0 = parser, 1 = emitter (wave-uniform) */
-	const uint32_t id = blockIdx.x + A.id_base;
-	const uint32_t blk = id / A.fpb, fi = id - blk * A.fpb;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t c = blockIdx.x; /* fragment of this chunk */
+	const uint32_t blk = A.blk_base + c / A.fpb, fi = c % A.fpb;
 	const uint32_t len = A.in_len[blk];
 	const uint32_t foff = fi * kFragment;
 	if (fi > 0 && foff >= len)
 		return;
+	if (GTAB && A.only_unparsed && A.rec_cnt[c] != kNoRecords)
+		return; /* second launch: only what the dense parser handed over */
 	const uint32_t n = min(len - foff, kFragment);
 	const int ws = fragment_power(n, A.p, A.mode);
 	const uint32_t shift = 33 - ws;
 	const uint8_t *src = A.in + A.in_off[blk] + foff;
+	uint2 *R = reinterpret_cast<uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
 
-	/* ---- LDS carve: window | hash table | conflict scratch | record ring | output staging ----
-	 * GTAB: the hash table lives in global memory (L2 / Infinity Cache resident: one private 2^p
-	 * bytes per workgroup of the launch) so that four fragments fit a CU's LDS instead of one. */
-	/* GWIN: the window is not staged at all: the parser and the emitter read the input where it
-	 * lies (L1/L2), which leaves ~8 KiB of LDS per fragment and lets 16 fragments share a CU. */
-	const uint32_t wbase = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
-	const uint32_t wlds = GWIN ? 0u : A.win_bytes;
-	const uint32_t *win32 = GWIN ? reinterpret_cast<const uint32_t *>(src - wbase)
-				     : reinterpret_cast<const uint32_t *>(smem);
-	const uint8_t *win8 = reinterpret_cast<const uint8_t *>(win32);
-	uint16_t *tab = GTAB ? A.gtab + ((uint64_t)blockIdx.x << (A.p - 1))
-			     : reinterpret_cast<uint16_t *>(smem + wlds);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + wlds + (GTAB ? 0u : (1u << A.p)));
-	uint32_t *S2 = S + A.s_entries; /* second filter (present iff s_shift != 0) */
-	uint32_t *ring = S + (A.s_shift ? 2 : 1) * A.s_entries; /* [2][64] records {lit_start, base, cand, copy_len} */
-	uint32_t *ring_cnt = ring + 2 * 64 * 4; /* [2] record counts, bit 16 = last batch */
-	uint8_t *stage = reinterpret_cast<uint8_t *>(ring) + kRingBytes;
-	/* GTAB: one bit per table slot, "written in this fragment".  A clear bit means the slot is
+	/* ---- LDS carve: table (or, TAB_GLOBAL, the occupancy bitmap) | conflict filters ----
+	 * per-fragment HBM region `tabs`: the dense ids (TAB_LDS_DENSE) or the table (TAB_GLOBAL) */
+	uint8_t *region = A.tabs + (uint64_t)c * A.tab_stride;
+	uint16_t *tab = GTAB ? reinterpret_cast<uint16_t *>(region) : reinterpret_cast<uint16_t *>(smem);
+	const uint16_t *ids = reinterpret_cast<const uint16_t *>(region);
+	/* TAB_GLOBAL: one bit per table slot, "written in this fragment".  A clear bit means the slot is
 	 * empty (the reference's zeroed table: candidate position 0) without touching memory, so the
 	 * global table is never cleared and never gathered for empty slots (41-50 % of the probes). */
-	uint32_t *occ = reinterpret_cast<uint32_t *>(stage + kStageBytes);
+	uint32_t *occ = reinterpret_cast<uint32_t *>(smem);
+	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
+	uint32_t *S2 = S + A.s_entries; /* second filter (present iff s_shift != 0) */
 	const uint32_t smask = A.s_entries - 1;
 
-	/* window: aligned 16 B chunks; byte i of the fragment sits at win8[wbase + i] */
-	if (!GWIN) {
-		const uint4 *g = reinterpret_cast<const uint4 *>(src - wbase);
-		uint4 *l = reinterpret_cast<uint4 *>(smem);
-		const uint32_t chunks = (wbase + n + 15) >> 4;
-		for (uint32_t k = tid; k < chunks; k += 128)
-			l[k] = g[k];
-	}
-	if (n >= kMargin) {
-		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
-		if (GTAB) {
-			uint4 *o4 = reinterpret_cast<uint4 *>(occ);
-			for (uint32_t k = tid; k < ((1u << ws) >> 8); k += 128) /* 2^(ws-1) bits = 2^(ws-4) bytes */
-				o4[k] = make_uint4(0, 0, 0, 0);
-		} else {
-			uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-			for (uint32_t k = tid; k < ((1u << ws) >> 4); k += 128)
-				t4[k] = make_uint4(0, 0, 0, 0);
-		}
-		uint4 *s4 = reinterpret_cast<uint4 *>(S);
-		for (uint32_t k = tid; k < (((A.s_shift ? 2 : 1) * A.s_entries) >> 2); k += 128)
-			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-	}
-	__syncthreads();
-
-	if (role == 1) {
-		/* =============================== EMITTER =============================== */
-		uint8_t *dst;
-		uint32_t hdr = 0;
-		if (fi == 0) {
-			dst = A.out + A.out_off[blk];
-			if (A.mode == CSNAPPY_HIP_STREAM) {
-				/* encode_varint32, csnappy_compress.c:46-73 */
-				hdr = varint_len(len);
-				if (lane < hdr)
-					dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < hdr ? 0x80u : 0u));
-				dst += hdr;
-			}
-		} else {
-			dst = A.scratch + (uint64_t)(blk * (uint64_t)(A.fpb - 1) + (fi - 1)) * kScratchSlot;
-		}
-		/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
-		 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
-		uint32_t gpos = 0, fill = 0;
-		uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
-
-		auto drain = [&](bool final) {
-			wave_lds_fence();
-			uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
-			const uint32_t end = sa + fill;
-			uint32_t first_full = 0;
-			if (sa > 0) {
-				const uint32_t hend = min(16u, end);
-				if (lane >= sa && lane < hend)
-					gbase[lane] = stage[lane];
-				first_full = 1;
-			}
-			const uint32_t nfull = end >> 4;
-			for (uint32_t c = first_full + lane; c < nfull; c += 64)
-				reinterpret_cast<uint4 *>(gbase)[c] = reinterpret_cast<const uint4 *>(stage)[c];
-			const uint32_t tail0 = nfull << 4;
-			const uint32_t tail = (end > tail0 && (nfull >= 1 || sa == 0)) ? end - tail0 : 0;
-			if (final) {
-				if (lane < tail)
-					gbase[tail0 + lane] = stage[tail0 + lane];
-				gpos += fill;
-				fill = 0;
-				sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
-			} else if (nfull >= 1) {
-				uint8_t keep = 0;
-				if (lane < tail)
-					keep = stage[tail0 + lane];
-				wave_lds_fence();
-				if (lane < tail)
-					stage[lane] = keep;
-				gpos += tail0 - sa;
-				fill = tail;
-				sa = 0;
-			}
-			wave_lds_fence();
-		};
-
-		for (uint32_t b = 0;; b ^= 1) {
-			__syncthreads(); /* batch b is published */
-			const uint32_t cw = ring_cnt[b];
-			const uint32_t nev = cw & 0xffff;
-			const bool last_batch = (cw >> 16) != 0;
-			/* ---- encode up to 64 records (EmitLiteral + EmitCopy, csnappy_compress.c:332-415) ---- */
-			uint32_t lit_start = 0, lit_len = 0, coff = 0, clen = 0;
-			if (lane < nev) {
-				const uint4 r = reinterpret_cast<const uint4 *>(ring)[b * 64 + lane];
-				lit_start = r.x;
-				lit_len = r.y - r.x; /* literal [lit_start, base) */
-				coff = r.y - r.z;    /* base - candidate */
-				clen = r.w;
-			}
-			const uint32_t lhdr = lit_len == 0 ? 0 : lit_len <= 60 ? 1 : lit_len <= 256 ? 2 : 3;
-			const CopyPlan cp = plan_copy(clen, coff);
-			const uint32_t mine = lhdr + lit_len + cp.bytes;
-			uint64_t bigmask = __ballot(mine > kBigRecord);
-			uint32_t total;
-			const uint32_t excl = wave_excl_scan(mine, lane, &total);
-			uint32_t seg_lo = 0; /* first record of the current run of small records */
-			while (nev) {
-				const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
-				if (seg_hi > seg_lo) {
-					/* stage small records [seg_lo, seg_hi) */
-					const uint32_t run_base = rdlane(excl, seg_lo);
-					const uint32_t run_bytes = (seg_hi < 64 ? rdlane(excl, seg_hi & 63) : total) - run_base;
-					const bool in_run = lane >= seg_lo && lane < seg_hi;
-					uint8_t *o = stage + sa + fill + (excl - run_base);
-					if (in_run) {
-						if (lhdr == 1) {
-							o[0] = (uint8_t)((lit_len - 1) << 2);
-						} else if (lhdr == 2) {
-							o[0] = (uint8_t)(60 << 2);
-							o[1] = (uint8_t)(lit_len - 1);
-						}
-					}
-					for (uint32_t j = 0; __ballot(in_run && j < lit_len); ++j)
-						if (in_run && j < lit_len)
-							o[lhdr + j] = win8[wbase + lit_start + j];
-					if (in_run && clen) {
-						uint8_t *q = o + lhdr + lit_len;
-						const uint8_t lo = (uint8_t)(coff & 0xff), hi = (uint8_t)(coff >> 8);
-						for (uint32_t k = 0; k < cp.k64; ++k) {
-							q[0] = 0xfe; /* COPY_2 | (63 << 2) */
-							q[1] = lo;
-							q[2] = hi;
-							q += 3;
-						}
-						if (cp.k60) {
-							q[0] = 0xee; /* COPY_2 | (59 << 2) */
-							q[1] = lo;
-							q[2] = hi;
-							q += 3;
-						}
-						if (cp.last < 12 && coff < 2048) {
-							q[0] = (uint8_t)(1 + ((cp.last - 4) << 2) + ((coff >> 8) << 5));
-							q[1] = lo;
-						} else {
-							q[0] = (uint8_t)(2 + ((cp.last - 1) << 2));
-							q[1] = lo;
-							q[2] = hi;
-						}
-					}
-					fill += run_bytes;
-				}
-				if (!bigmask)
-					break;
-				/* ---- a big record: drain the staging, write it straight to HBM ---- */
-				const uint32_t e = first_lane(bigmask);
-				bigmask &= bigmask - 1;
-				drain(true);
-				const uint32_t ls = rdlane(lit_start, e), ll = rdlane(lit_len, e);
-				const uint32_t lh = rdlane(lhdr, e), co = rdlane(coff, e), cl = rdlane(clen, e);
-				const uint32_t k64 = rdlane(cp.k64, e), k60 = rdlane(cp.k60, e), last = rdlane(cp.last, e);
-				const uint32_t cbytes = rdlane(cp.bytes, e);
-				uint8_t *o = dst + gpos;
-				if (lane == 0) {
-					const uint32_t v = ll - 1;
-					if (lh == 1) {
-						o[0] = (uint8_t)(v << 2);
-					} else if (lh == 2) {
-						o[0] = (uint8_t)(60 << 2);
-						o[1] = (uint8_t)v;
-					} else if (lh == 3) {
-						o[0] = (uint8_t)(61 << 2);
-						o[1] = (uint8_t)(v & 0xff);
-						o[2] = (uint8_t)(v >> 8);
-					}
-				}
-				{
-					/* literal payload: destination-aligned dwords from the LDS window */
-					uint8_t *d = o + lh;
-					const uint32_t head = min(ll, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
-					if (lane < head)
-						d[lane] = win8[wbase + ls + lane];
-					const uint32_t words = (ll - head) >> 2;
-					uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
-					for (uint32_t k = lane; k < words; k += 64)
-						d32[k] = win_rd32<GWIN>(win32, wbase + ls + head + 4 * k);
-					const uint32_t t0 = head + 4 * words;
-					if (t0 + lane < ll)
-						d[t0 + lane] = win8[wbase + ls + t0 + lane];
-				}
-				if (cl) {
-					uint8_t *q = o + lh + ll;
-					const uint32_t body = 3 * (k64 + k60);
-					for (uint32_t t = lane; t < cbytes; t += 64) {
-						uint8_t bb;
-						if (t < body) {
-							const uint32_t r = t % 3;
-							bb = r == 0 ? (t < 3 * k64 ? 0xfe : 0xee) : r == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
-						} else {
-							const uint32_t r = t - body;
-							const bool two = last < 12 && co < 2048;
-							bb = r == 0 ? (two ? (uint8_t)(1 + ((last - 4) << 2) + ((co >> 8) << 5))
-									   : (uint8_t)(2 + ((last - 1) << 2)))
-							     : r == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
-						}
-						q[t] = bb;
-					}
-				}
-				gpos += lh + ll + cbytes;
-				sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
-				seg_lo = e + 1;
-			}
-			if (last_batch)
-				break;
-			if (fill >= kFlushAt)
-				drain(false);
-		}
-		drain(true);
-		if (lane == 0) {
-			A.frag_len[id] = gpos;
-			if (A.fpb == 1)
-				A.out_len[blk] = hdr + gpos;
-		}
-		return;
-	}
-
-	/* ================================== PARSER ================================== */
-	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t_pub = 0, t0 = 0, t1 = 0;
+	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t0 = 0, t1 = 0;
 	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
 	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0, t_pre = 0, t_loop_end = 0;
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
-	uint4 *ring4 = reinterpret_cast<uint4 *>(ring);
-	uint32_t nev = 0, batch = 0; /* records queued in the current batch */
-	uint32_t next_emit = 0;      /* csnappy_compress.c:496 */
+
+	if (n >= kMargin) {
+		if (DENSE) {
+			/* ---- prologue: dense bucket ids (see the header comment) ----
+			 * seen1/seen2: slot hit at least once / at least twice; pref: buckets below a word */
+			const uint32_t nwords = (1u << (ws - 1)) >> 5; /* >= 8 */
+			uint32_t *seen1 = reinterpret_cast<uint32_t *>(smem), *seen2 = seen1 + nwords;
+			uint16_t *pref = reinterpret_cast<uint16_t *>(seen2 + nwords);
+			for (uint32_t k = lane; k < 2 * nwords; k += 64)
+				seen1[k] = 0;
+			wave_lds_fence();
+			const uint32_t npos = n - 3; /* positions that have four bytes */
+			/* eight consecutive positions per lane and iteration: the 16 bytes at i cover their
+			 * hashes; the next iteration's bytes are requested before this one's are used */
+			auto load16 = [&](uint32_t i) -> uint4 {
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (i + 16 <= n) {
+					__builtin_memcpy(&v, src + i, 16);
+				} else if (i < n) {
+					uint32_t w[4] = { 0, 0, 0, 0 };
+					for (uint32_t k = 0; i + k < n; ++k)
+						w[k >> 2] |= (uint32_t)src[i + k] << (8 * (k & 3));
+					v = make_uint4(w[0], w[1], w[2], w[3]);
+				}
+				return v;
+			};
+			auto hash8 = [&](const uint4 &v, uint32_t hh[8]) {
+				const uint32_t w0 = v.x, w1 = v.y, w2 = v.z;
+				hh[0] = (w0 * kHashMul) >> shift;
+				hh[1] = (__builtin_amdgcn_alignbyte(w1, w0, 1) * kHashMul) >> shift;
+				hh[2] = (__builtin_amdgcn_alignbyte(w1, w0, 2) * kHashMul) >> shift;
+				hh[3] = (__builtin_amdgcn_alignbyte(w1, w0, 3) * kHashMul) >> shift;
+				hh[4] = (w1 * kHashMul) >> shift;
+				hh[5] = (__builtin_amdgcn_alignbyte(w2, w1, 1) * kHashMul) >> shift;
+				hh[6] = (__builtin_amdgcn_alignbyte(w2, w1, 2) * kHashMul) >> shift;
+				hh[7] = (__builtin_amdgcn_alignbyte(w2, w1, 3) * kHashMul) >> shift;
+			};
+			{
+				uint4 nxt = load16(8 * lane);
+				for (uint32_t b0 = 0; b0 < npos; b0 += 512) {
+					const uint32_t i = b0 + 8 * lane;
+					const uint32_t cntp = i < npos ? min(8u, npos - i) : 0;
+					const uint4 v = nxt;
+					if (b0 + 512 < npos)
+						nxt = load16(i + 512);
+					uint32_t hh[8], old[8];
+					hash8(v, hh);
+#pragma unroll
+					for (uint32_t k = 0; k < 8; ++k)
+						old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+#pragma unroll
+					for (uint32_t k = 0; k < 8; ++k)
+						if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
+							atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
+				}
+			}
+			wave_lds_fence();
+			const uint32_t per = max(1u, nwords >> 6);
+			uint32_t mine = 0;
+			for (uint32_t k = 0; k < per; ++k) {
+				const uint32_t w = lane * per + k;
+				if (w < nwords)
+					mine += (uint32_t)__builtin_popcount(seen2[w]);
+			}
+			uint32_t nb;
+			uint32_t run = wave_excl_scan(mine, lane, &nb);
+			if (nb > A.dense_cap) {
+				/* more buckets than the LDS table holds: the global-table launch takes it */
+				if (lane == 0)
+					A.rec_cnt[c] = kNoRecords;
+				return;
+			}
+			for (uint32_t k = 0; k < per; ++k) {
+				const uint32_t w = lane * per + k;
+				if (w < nwords) {
+					pref[w] = (uint16_t)run;
+					run += (uint32_t)__builtin_popcount(seen2[w]);
+				}
+			}
+			wave_lds_fence();
+			uint16_t *wids = reinterpret_cast<uint16_t *>(region);
+			{
+				uint4 nxt = load16(8 * lane);
+				for (uint32_t b0 = 0; b0 < npos; b0 += 512) {
+					const uint32_t i = b0 + 8 * lane;
+					const uint32_t cntp = i < npos ? min(8u, npos - i) : 0;
+					const uint4 v = nxt;
+					if (b0 + 512 < npos)
+						nxt = load16(i + 512);
+					uint32_t hh[8], id[8];
+					hash8(v, hh);
+#pragma unroll
+					for (uint32_t k = 0; k < 8; ++k) {
+						const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
+						const uint32_t b = 1u << (hh[k] & 31);
+						id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
+					}
+					if (cntp == 8) {
+						*reinterpret_cast<uint4 *>(wids + i) =
+							make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
+								   id[6] | (id[7] << 16));
+					} else {
+#pragma unroll
+						for (uint32_t k = 0; k < 7; ++k)
+							if (k < cntp)
+								wids[i + k] = (uint16_t)id[k];
+					}
+				}
+			}
+			wave_lds_fence();
+			/* the ids are read back by this wave only (same CU, same L1/L2 path, program order);
+			 * make the stores leave the wave before the first load of them is issued */
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		}
+		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
+		{
+			const uint32_t zb = GTAB ? (1u << ws) >> 4 : DENSE ? 2 * A.dense_cap : 1u << ws;
+			uint4 *z4 = reinterpret_cast<uint4 *>(smem);
+			for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
+				z4[k] = make_uint4(0, 0, 0, 0);
+			uint4 *s4 = reinterpret_cast<uint4 *>(S);
+			for (uint32_t k = lane; k < (((A.s_shift ? 2 : 1) * A.s_entries) >> 2); k += 64)
+				s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+		}
+		wave_lds_fence();
+	}
+
+	/* ================================== PARSER ================================== */
+	uint32_t nev = 0;       /* records written */
+	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
 	const uint64_t lt_mask = (1ull << lane) - 1;
 
-	auto publish = [&](bool last) {
-		unsigned long long tp = 0;
-		if (PROF)
-			tp = __builtin_amdgcn_s_memtime();
-		if (lane == 0)
-			ring_cnt[batch] = nev | (last ? 0x10000u : 0u);
-		__syncthreads();
-		batch ^= 1;
-		nev = 0;
-		if (PROF)
-			t_pub += __builtin_amdgcn_s_memtime() - tp;
-	};
 	/* one record produced by uniform code: {literal [lit_start, base), copy(base - cnd, clen)} */
 	auto add_record = [&](uint32_t lit_start, uint32_t base, uint32_t cnd, uint32_t clen) {
 		if (lane == 0)
-			ring4[batch * 64 + nev] = make_uint4(lit_start, base, cnd, clen);
-		if (++nev == 64)
-			publish(false);
+			R[nev] = pack_record(lit_start, base, cnd, clen);
+		++nev;
 	};
 	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
 	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
@@ -562,13 +418,16 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			uint32_t m8 = 0;
 			bool term = true;
 			if (o < lim) {
-				if (GWIN && o + 8 > lim) {
+				if (o + 8 > lim) {
 					/* the last few bytes of the fragment: never read past the input */
-					while (m8 < lim - o && win8[wbase + ma + o + m8] == win8[wbase + mb + o + m8])
+					while (m8 < lim - o && src[ma + o + m8] == src[mb + o + m8])
 						++m8;
 					term = true;
 				} else {
-					const uint64_t x = win_rd64<GWIN>(win32, wbase + ma + o) ^ win_rd64<GWIN>(win32, wbase + mb + o);
+					uint64_t xa, xb;
+					__builtin_memcpy(&xa, src + ma + o, 8);
+					__builtin_memcpy(&xb, src + mb + o, 8);
+					const uint64_t x = xa ^ xb;
 					m8 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
 					m8 = min(m8, lim - o);
 					term = m8 < 8 || o + 8 >= lim;
@@ -590,15 +449,17 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 		uint32_t s = 1, qi = 0; /* scan start and index of the next scan probe */
 		uint32_t epoch = 0x03ffffffu;
 		bool fin = false;
-		const uint32_t chk0 = ((win_rd32<GWIN>(win32, wbase) * kHashMul) >> (shift - 1)) & 1u;
+		uint32_t first4;
+		__builtin_memcpy(&first4, src, 4);
+		const uint32_t chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
 
-		/* lane positions of a step; the 16 bytes at the lane's position are fetched one step
-		 * ahead (as soon as the cursor of the next step is known) to take that LDS round trip
-		 * off the dependent chain */
+		/* lane positions of a step; the 16 bytes at the lane's position (and its bucket id) are
+		 * fetched one step ahead, as soon as the cursor of the next step is known, to take that
+		 * round trip off the dependent chain */
 		bool sparse;
 		uint32_t p0, pos;
 		bool valid;
-		uint32_t raw[5], rsh = 0; /* the five aligned dwords that cover the lane's 16 bytes */
+		uint32_t raw[4], sid = kNoBucket;
 		auto place = [&]() {
 			sparse = spec == 0 && qi >= 32;
 			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
@@ -613,27 +474,20 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			}
 			if (!valid)
 				pos = 0;
-			rsh = wbase + pos;
-			if (GWIN) {
-				/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others must
-				 * not read at all: the input may end right behind a 15-byte fragment */
-				uint4 v = make_uint4(0, 0, 0, 0);
-				if (valid)
-					__builtin_memcpy(&v, win8 + rsh, 16);
-				raw[0] = v.x;
-				raw[1] = v.y;
-				raw[2] = v.z;
-				raw[3] = v.w;
-				raw[4] = 0;
-				rsh = 0;
-			} else {
-				const uint32_t d = rsh >> 2;
-				raw[0] = win32[d];
-				raw[1] = win32[d + 1];
-				raw[2] = win32[d + 2];
-				raw[3] = win32[d + 3];
-				raw[4] = win32[d + 4];
+			/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others must
+			 * not read at all: the input may end right behind a 15-byte fragment */
+			uint4 v = make_uint4(0, 0, 0, 0);
+			uint16_t idv = (uint16_t)kNoBucket;
+			if (valid) {
+				__builtin_memcpy(&v, src + pos, 16);
+				if (DENSE)
+					idv = ids[pos];
 			}
+			raw[0] = v.x;
+			raw[1] = v.y;
+			raw[2] = v.z;
+			raw[3] = v.w;
+			sid = idv;
 		};
 		place();
 		if (PROF)
@@ -651,24 +505,25 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint32_t p0_c = p0, pos_c = pos;
 			const bool valid_c = valid;
 			uint32_t cb[4];
-			const uint32_t me0 = __builtin_amdgcn_alignbyte(raw[1], raw[0], rsh);
-			const uint32_t me1 = __builtin_amdgcn_alignbyte(raw[2], raw[1], rsh);
-			const uint32_t me2 = __builtin_amdgcn_alignbyte(raw[3], raw[2], rsh);
-			const uint32_t me3 = __builtin_amdgcn_alignbyte(raw[4], raw[3], rsh);
+			const uint32_t me0 = raw[0], me1 = raw[1], me2 = raw[2], me3 = raw[3];
 			const uint32_t prod = me0 * kHashMul;
-			const uint32_t h = prod >> shift;
+			/* slot = what identifies the lane's table entry: the dense bucket id or the hash */
+			const uint32_t slot = DENSE ? sid : prod >> shift;
+			/* lanes that take part in the table at all (a lone position's slot is never read) */
+			const bool tabbed = DENSE ? valid_c && slot != kNoBucket : valid_c;
 			/* The uint16 table entries hold 15-bit positions; bit 15 carries one more bit of the
 			 * hash product of the bytes at that position.  Equal 4 bytes imply equal products,
 			 * so a candidate whose check bit differs cannot match and its bytes need not be
 			 * fetched (an empty slot stands for position 0: its check bit is that of F[0..4)). */
 			const uint32_t chk = (prod >> (shift - 1)) & 1u;
 			/* slot sharing inside a step is detected with one or two small filters keyed by
-			 * different bits of the hash: a lane is cut only if BOTH report an earlier lane
+			 * different bits of the slot: a lane is flagged only if BOTH report an earlier lane
 			 * (two lanes with the same slot collide in both; a false alarm needs two
 			 * independent key collisions) */
-			const uint32_t key = h & smask;
-			const uint32_t key2 = (h >> A.s_shift) & smask;
-			if (valid_c) {
+			const uint32_t key = slot & smask;
+			const uint32_t key2 = DENSE ? ((slot >> A.s_shift) ^ (slot << (A.s_shift - 5))) & smask
+						    : (slot >> A.s_shift) & smask;
+			if (tabbed) {
 				atomicMin(&S[key], (epoch << 6) | lane);
 				if (A.s_shift)
 					atomicMin(&S2[key2], (epoch << 6) | lane);
@@ -677,44 +532,32 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
 			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
 			uint32_t cand = 0, first_same;
-			int c1, v, ulim;
-			uint64_t cmask; /* flagged lanes */
-			if (GTAB) {
-				/* the table (and window) gathers go to L2/HBM: resolve the slot sharing first
-				 * (LDS only) so that flagged lanes and lanes behind a cut do not gather at all */
-				wave_lds_fence();
-				first_same = S[key] & 63u; /* lowest valid lane with my slot key */
-				if (A.s_shift)
-					first_same = max(first_same, S2[key2] & 63u);
-				const bool flagged = valid_c && first_same < lane;
-				cmask = __ballot(flagged);
-				const uint64_t imask = ~__ballot(valid_c);
-				c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
-				v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
-				ulim = sparse_c ? min(c1, v) : min(v, (int)A.width);
-				if ((int)lane < ulim && !flagged && ((occ[h >> 5] >> (h & 31)) & 1u))
-					cand = tab[h];
-			} else {
-				cand = tab[h];
-				wave_lds_fence();
-				first_same = S[key] & 63u;
-				if (A.s_shift)
-					first_same = max(first_same, S2[key2] & 63u);
-			}
-			const bool maybe = (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
+			if (!GTAB && tabbed)
+				cand = tab[slot];
+			wave_lds_fence();
+			first_same = S[key] & 63u; /* lowest lane with my slot key */
+			if (A.s_shift)
+				first_same = max(first_same, S2[key2] & 63u);
+			const bool flagged = tabbed && first_same < lane;
+			uint64_t cmask = __ballot(flagged); /* flagged lanes */
+			const uint64_t imask = ~__ballot(valid_c);
+			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
+			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
+			int ulim = sparse_c ? min(c1, v) : v;
+			/* TAB_GLOBAL: the table gathers go to L2/HBM, so flagged lanes, lanes behind a cut and
+			 * empty slots do not gather at all */
+			if (GTAB && (int)lane < ulim && !flagged && ((occ[slot >> 5] >> (slot & 31)) & 1u))
+				cand = tab[slot];
+			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
 			cand &= 0x7fffu;
 			cb[0] = cb[1] = cb[2] = cb[3] = 0;
-			if (GWIN) {
-				if ((int)lane < ulim && maybe && !((cmask >> lane) & 1)) {
-					uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
-					__builtin_memcpy(&w4, win8 + wbase + cand, 16);
-					cb[0] = w4.x;
-					cb[1] = w4.y;
-					cb[2] = w4.z;
-					cb[3] = w4.w;
-				}
-			} else {
-				lds_rd128(win32, wbase + cand, cb);
+			if ((int)lane < ulim && maybe && !(GTAB && flagged)) {
+				uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
+				__builtin_memcpy(&w4, src + cand, 16);
+				cb[0] = w4.x;
+				cb[1] = w4.y;
+				cb[2] = w4.z;
+				cb[3] = w4.w;
 			}
 			/* lane-local match length, capped at kLocalMatch (the end of the fragment is at least
 			 * 16 bytes away from every valid probe position) */
@@ -722,17 +565,8 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
 			uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
 				      : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
-			if (!maybe)
-				mlen = 0;
-			if (!GTAB) {
-				cmask = __ballot(valid_c && first_same < lane);
-				const uint64_t imask = ~__ballot(valid_c);
-				c1 = cmask ? (int)first_lane(cmask) : 64;
-				v = imask ? (int)first_lane(imask) : 64;
-				ulim = sparse_c ? min(c1, v) : v;
-			} else if ((cmask >> lane) & 1) {
-				mlen = 0; /* nothing was gathered for a flagged lane */
-			}
+			if (!maybe || (GTAB && flagged))
+				mlen = 0; /* (nothing was gathered for a flagged lane of the global placement) */
 			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
 			epoch--;
 			if (PROF) {
@@ -746,6 +580,11 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 			uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
 			const uint32_t emit0 = next_emit;
 			const uint32_t nev0 = nev;
+			uint2 rec = make_uint2(0, 0);
+			bool rec_mine = false;
+			uint32_t rec_idx = 0;
+			bool wide_rec = false;
+			uint32_t emit1 = 0, wbase_l = 0, wcnd = 0;
 			if (sparse_c) {
 				/* ---- sparse step: ends at its first match ---- */
 				if (matchmask == 0) {
@@ -784,15 +623,14 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
 				const uint64_t special = widemask | flagmask; /* stops that are not plain matches */
 				uint32_t nx; /* ... | 128 when that next stop is a special lane */
-				auto next_stop = [&]() {
+				{
 					const uint64_t rest = cl < 64 ? stopmask >> cl : 0;
 					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
 					const uint32_t j = cl + fm;
 					const bool in = (fm <= 32 && j <= 63);
 					const uint32_t sp = in ? (uint32_t)(special >> j) & 1u : 0u;
 					nx = (int)cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
-				};
-				next_stop();
+				}
 				int a, zl;      /* first lane that may probe, lane of scan index 0 */
 				uint32_t seg_s; /* scan start of the current segment */
 				if (spec == 2) {
@@ -814,13 +652,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				int last = -1;
 				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
 				uint32_t wide_len = 0;
-				/* the same as next_stop() for one match on the scalar unit: c = lane behind it */
-				auto scalar_next = [&](int c) -> uint32_t {
-					if (c >= ulim)
+				/* the same as nx for one match on the scalar unit: c = lane behind it */
+				auto scalar_next = [&](int cc) -> uint32_t {
+					if (cc >= ulim)
 						return 64u;
-					const uint64_t rest = stopmask >> c;
+					const uint64_t rest = stopmask >> cc;
 					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-					const uint32_t j = (uint32_t)c + fm;
+					const uint32_t j = (uint32_t)cc + fm;
 					if (fm > 32 || j > 63)
 						return 65u;
 					return j | (((uint32_t)(special >> j) & 1u) << 7);
@@ -835,14 +673,14 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 								/* ---- the chain probes a flagged lane ----
 								 * Its candidate is the latest position inserted for its slot: the
 								 * highest lane below it that this step inserts (not strictly inside a
-								 * copy of the chain) and that has the same hash -- whose bytes are
-								 * that lane's own 16 bytes -- else the table value.  (Global
-								 * placements did not gather the latter: cut the step here.) */
+								 * copy of the chain) and that has the same slot -- whose bytes are
+								 * that lane's own 16 bytes -- else the table value.  (The global
+								 * placement did not gather the latter: cut the step here.) */
 								const uint64_t below = taken & lt_mask;
 								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
 								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
 								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(below != 0 && lane + 1 < cprev);
-								const uint64_t same = __ballot(h == rdlane(h, i)) & ins;
+								const uint64_t same = __ballot(tabbed && slot == rdlane(slot, i)) & ins;
 								if (same) {
 									const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
 									const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
@@ -935,7 +773,6 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 					if (PROF)
 						n_match += __builtin_popcountll(taken);
 				}
-				uint32_t wbase_l = 0, wcnd = 0;
 				if (stop == 66) {
 					/* the extended match runs past the usable lanes: it ends the step */
 					wbase_l = p0_c + (uint32_t)i;
@@ -968,9 +805,11 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 						qi = (uint32_t)(e + 1 - zl);
 					}
 				}
-				const uint32_t emit1 = next_emit; /* literal start of a wide record */
-				if (stop == 66)
+				emit1 = next_emit; /* literal start of a wide record */
+				if (stop == 66) {
 					next_emit = ip;
+					wide_rec = true;
+				}
 				if (PROF) {
 					const unsigned long long t = __builtin_amdgcn_s_memtime();
 					t_stop += t - tq;
@@ -991,26 +830,13 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 					const bool hasprev = below != 0;
 					const uint32_t jprev = hasprev ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
 					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-					const bool mine = (taken >> lane) & 1;
+					rec_mine = (taken >> lane) & 1;
 					const uint32_t lit_start = hasprev ? p0_c + cprev : emit0;
 					inside = hasprev && lane + 1 < cprev; /* strictly inside a taken copy: never inserted */
-					const uint32_t idx = nev0 + (uint32_t)__builtin_popcountll(below);
-					const uint32_t ntaken = (uint32_t)__builtin_popcountll(taken);
-					const uint4 rec = make_uint4(lit_start, p0_c + lane, cand, mlen);
-					if (mine && idx < 64)
-						ring4[batch * 64 + idx] = rec;
-					if (nev0 + ntaken >= 64) {
-						nev = 64;
-						publish(false);
-						if (mine && idx >= 64)
-							ring4[batch * 64 + idx - 64] = rec;
-						nev = nev0 + ntaken - 64;
-					} else {
-						nev = nev0 + ntaken;
-					}
+					rec_idx = nev0 + (uint32_t)__builtin_popcountll(below);
+					rec = pack_record(lit_start, p0_c + lane, cand, mlen);
+					nev = nev0 + (uint32_t)__builtin_popcountll(taken);
 				}
-				if (stop == 66)
-					add_record(emit1, wbase_l, wcnd, ip - wbase_l);
 				if (PROF)
 					t_rec += __builtin_amdgcn_s_memtime() - tq;
 			}
@@ -1018,15 +844,18 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				t0 = __builtin_amdgcn_s_memtime();
 				t_walk += t0 - t1;
 			}
-			/* commit table[hash] = position for every lane that was probed or inserted
-			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
-			 * of the table stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
+			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
 			 * behind the stores (at the loop's back edge, where the compiler would put it) also sits
 			 * out the stores' round trip -- once per step, on the dependent chain. */
-			if (GWIN)
-				asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
-			bool commit = (int)lane <= e_final && !inside;
+			asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(sid));
+			if (rec_mine)
+				R[rec_idx] = rec;
+			if (wide_rec)
+				add_record(emit1, wbase_l, wcnd, ip - wbase_l);
+			/* commit table[slot] = position for every lane that was probed or inserted
+			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
+			bool commit = (int)lane <= e_final && !inside && tabbed;
 			{
 				/* of several committed lanes with one slot only the last may write (flagged lanes
 				 * that the chain inserted; sparse steps never commit one) */
@@ -1036,15 +865,15 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 				while (fl) {
 					const uint32_t x = first_lane(fl);
 					fl &= fl - 1;
-					dead |= __ballot(h == rdlane(h, x)) & cm & ((1ull << x) - 1);
+					dead |= __ballot(slot == rdlane(slot, x)) & cm & ((1ull << x) - 1);
 				}
 				if ((dead >> lane) & 1)
 					commit = false;
 			}
 			if (commit) {
-				tab[h] = (uint16_t)(pos_c | (chk << 15));
+				tab[slot] = (uint16_t)(pos_c | (chk << 15));
 				if (GTAB)
-					atomicOr(&occ[h >> 5], 1u << (h & 31));
+					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
 			}
 			wave_lds_fence();
 			if (PROF)
@@ -1057,14 +886,14 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
 	if (next_emit < n)
 		add_record(next_emit, n, n, 0);
-	publish(true);
+	if (lane == 0)
+		A.rec_cnt[c] = nev;
 	if (PROF && lane == 0) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 		atomicAdd(&A.prof[0], t_end - t_begin);
 		atomicAdd(&A.prof[1], t_vec);
 		atomicAdd(&A.prof[2], t_walk);
 		atomicAdd(&A.prof[3], t_commit);
-		atomicAdd(&A.prof[4], t_pub);
 		atomicAdd(&A.prof[5], n_steps);
 		atomicAdd(&A.prof[6], n_match);
 		atomicAdd(&A.prof[7], n_wide);
@@ -1079,85 +908,314 @@ __device__ __forceinline__ void compress_fragment_body(const CompressArgs &A)
 	}
 }
 
-extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments(CompressArgs A)
+/* table indexed by the hash, in LDS (tables of <= 8 KiB) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments(CompressArgs A)
 {
-	compress_fragment_body<false, false, false>(A);
+	parse_fragment_body<false, TAB_LDS_HASH>(A);
 }
 
-/* hash table in global memory (more fragments per CU when the table would fill the LDS) */
-extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab(CompressArgs A)
+/* table indexed by dense bucket ids, in LDS (the default for tables that would not fit) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense(CompressArgs A)
 {
-	compress_fragment_body<false, true, false>(A);
+	parse_fragment_body<false, TAB_LDS_DENSE>(A);
 }
 
-/* hash table in global memory and the window read in place (no LDS copy of the input) */
-extern "C" __global__ void __launch_bounds__(128, 6) snappy_compress_fragments_gwin(CompressArgs A)
+/* full table in global memory (fragments with more buckets than the dense LDS table holds) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(CompressArgs A)
 {
-	compress_fragment_body<false, true, true>(A);
+	parse_fragment_body<false, TAB_GLOBAL>(A);
 }
 
 /* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
-extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_prof(CompressArgs A)
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_prof(CompressArgs A)
 {
-	compress_fragment_body<true, false, false>(A);
+	parse_fragment_body<true, TAB_LDS_HASH>(A);
 }
 
-extern "C" __global__ void __launch_bounds__(128) snappy_compress_fragments_gtab_prof(CompressArgs A)
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_prof(CompressArgs A)
 {
-	compress_fragment_body<true, true, false>(A);
+	parse_fragment_body<true, TAB_LDS_DENSE>(A);
 }
 
-extern "C" __global__ void __launch_bounds__(128, 6) snappy_compress_fragments_gwin_prof(CompressArgs A)
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_prof(CompressArgs A)
 {
-	compress_fragment_body<true, true, true>(A);
+	parse_fragment_body<true, TAB_GLOBAL>(A);
 }
 
 /* ==========================================================================================
- * STITCH: move fragments 1.. of every block behind fragment 0 and write the block length.
- * (The reference gets this for free from its sequential pointer chain, csnappy_compress.c:647-653.)
+ * COMPRESS, kernel 2 of 2: snappy_emit_blocks -- one workgroup (4 waves) per block
+ *
+ * Turns the parser's records into the block's bytes: EmitLiteral / EmitCopy
+ * (csnappy_compress.c:332-415), the varint length prefix (:46-73) and the pointer chain that
+ * puts fragment k+1 behind fragment k (:647-653).  Per fragment: the encoded size of every
+ * record (one pass, 64 records per wave), a scan of the per-64-record totals, then every wave
+ * encodes its 64-record chunks into its own LDS staging and flushes them with aligned
+ * 16 B/lane stores at the chunk's final place in the block's slot -- nothing is moved twice.
  * ======================================================================================== */
-extern "C" __global__ void __launch_bounds__(256) snappy_stitch_blocks(CompressArgs A)
+struct RecFields {
+	uint32_t lit_start, lit_len, coff, clen, lhdr, mine;
+	CopyPlan cp;
+};
+
+DEVINL RecFields decode_record(uint2 r, bool live)
 {
-	__shared__ uint32_t red[4];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t id = blockIdx.x;
-	const uint32_t blk = id / A.fpb, fi = id - blk * A.fpb;
+	RecFields f;
+	f.lit_start = r.y >> 16;
+	f.lit_len = live ? (r.x & 0xffffu) - f.lit_start : 0; /* literal [lit_start, base) */
+	f.coff = (r.x & 0xffffu) - (r.x >> 16);              /* base - candidate */
+	f.clen = live ? r.y & 0xffffu : 0;
+	f.lhdr = f.lit_len == 0 ? 0 : f.lit_len <= 60 ? 1 : f.lit_len <= 256 ? 2 : 3;
+	f.cp = plan_copy(f.clen, f.coff);
+	f.mine = f.lhdr + f.lit_len + f.cp.bytes;
+	return f;
+}
+
+/* encode records [first, first + nev) of one fragment to dst (their final place); src = the
+ * fragment's input, avail = input bytes readable from src (to the end of the block) */
+DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8_t *src, uint32_t avail,
+		       uint8_t *dst, uint8_t *stage, uint32_t lane)
+{
+	/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
+	 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
+	uint32_t gpos = 0, fill = 0;
+	uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+
+	auto drain = [&]() {
+		wave_lds_fence();
+		uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
+		const uint32_t end = sa + fill;
+		uint32_t first_full = 0;
+		if (sa > 0) {
+			const uint32_t hend = min(16u, end);
+			if (lane >= sa && lane < hend)
+				gbase[lane] = stage[lane];
+			first_full = 1;
+		}
+		const uint32_t nfull = end >> 4;
+		for (uint32_t cc = first_full + lane; cc < nfull; cc += 64)
+			reinterpret_cast<uint4 *>(gbase)[cc] = reinterpret_cast<const uint4 *>(stage)[cc];
+		const uint32_t tail0 = nfull << 4;
+		const uint32_t tail = (end > tail0 && (nfull >= 1 || sa == 0)) ? end - tail0 : 0;
+		if (lane < tail)
+			gbase[tail0 + lane] = stage[tail0 + lane];
+		gpos += fill;
+		fill = 0;
+		sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
+		wave_lds_fence();
+	};
+
+	const bool live = lane < nev;
+	const uint2 r = live ? R[first + lane] : make_uint2(0, 0);
+	const RecFields f = decode_record(r, live);
+	const uint32_t lit_start = f.lit_start, lit_len = f.lit_len, coff = f.coff, clen = f.clen;
+	const uint32_t lhdr = f.lhdr, mine = f.mine;
+	const CopyPlan cp = f.cp;
+	uint64_t bigmask = __ballot(mine > kBigRecord);
+	uint32_t total;
+	const uint32_t excl = wave_excl_scan(mine, lane, &total);
+	/* literal payload of a small record (< 32 bytes): two 16 B loads, taken before any staging */
+	uint32_t lw[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	if (live && mine <= kBigRecord && lit_len) {
+		if (lit_start + 32 <= avail) {
+			uint4 a, b;
+			__builtin_memcpy(&a, src + lit_start, 16);
+			__builtin_memcpy(&b, src + lit_start + 16, 16);
+			lw[0] = a.x; lw[1] = a.y; lw[2] = a.z; lw[3] = a.w;
+			lw[4] = b.x; lw[5] = b.y; lw[6] = b.z; lw[7] = b.w;
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < 32; ++k)
+				if (k < lit_len)
+					lw[k >> 2] |= (uint32_t)src[lit_start + k] << (8 * (k & 3));
+		}
+	}
+	uint32_t seg_lo = 0; /* first record of the current run of small records */
+	while (nev) {
+		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
+		if (seg_hi > seg_lo) {
+			/* stage small records [seg_lo, seg_hi) */
+			const uint32_t run_base = rdlane(excl, seg_lo);
+			const uint32_t run_bytes = (seg_hi < 64 ? rdlane(excl, seg_hi & 63) : total) - run_base;
+			const bool in_run = lane >= seg_lo && lane < seg_hi;
+			uint8_t *o = stage + sa + fill + (excl - run_base);
+			if (in_run) {
+				if (lhdr == 1) {
+					o[0] = (uint8_t)((lit_len - 1) << 2);
+				} else if (lhdr == 2) {
+					o[0] = (uint8_t)(60 << 2);
+					o[1] = (uint8_t)(lit_len - 1);
+				}
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k) {
+				if (!__ballot(in_run && 4 * k < lit_len))
+					break;
+				if (in_run && 4 * k < lit_len) {
+					uint8_t *q = o + lhdr + 4 * k;
+					const uint32_t w = lw[k], rem = lit_len - 4 * k;
+					q[0] = (uint8_t)w;
+					if (rem > 1)
+						q[1] = (uint8_t)(w >> 8);
+					if (rem > 2)
+						q[2] = (uint8_t)(w >> 16);
+					if (rem > 3)
+						q[3] = (uint8_t)(w >> 24);
+				}
+			}
+			if (in_run && clen) {
+				uint8_t *q = o + lhdr + lit_len;
+				const uint8_t lo = (uint8_t)(coff & 0xff), hi = (uint8_t)(coff >> 8);
+				for (uint32_t k = 0; k < cp.k64; ++k) {
+					q[0] = 0xfe; /* COPY_2 | (63 << 2) */
+					q[1] = lo;
+					q[2] = hi;
+					q += 3;
+				}
+				if (cp.k60) {
+					q[0] = 0xee; /* COPY_2 | (59 << 2) */
+					q[1] = lo;
+					q[2] = hi;
+					q += 3;
+				}
+				if (cp.last < 12 && coff < 2048) {
+					q[0] = (uint8_t)(1 + ((cp.last - 4) << 2) + ((coff >> 8) << 5));
+					q[1] = lo;
+				} else {
+					q[0] = (uint8_t)(2 + ((cp.last - 1) << 2));
+					q[1] = lo;
+					q[2] = hi;
+				}
+			}
+			fill += run_bytes;
+		}
+		if (!bigmask)
+			break;
+		/* ---- a big record: drain the staging, write it straight to HBM ---- */
+		const uint32_t e = first_lane(bigmask);
+		bigmask &= bigmask - 1;
+		drain();
+		const uint32_t ls = rdlane(lit_start, e), ll = rdlane(lit_len, e);
+		const uint32_t lh = rdlane(lhdr, e), co = rdlane(coff, e), cl = rdlane(clen, e);
+		const uint32_t k64 = rdlane(cp.k64, e), k60 = rdlane(cp.k60, e), last = rdlane(cp.last, e);
+		const uint32_t cbytes = rdlane(cp.bytes, e);
+		uint8_t *o = dst + gpos;
+		if (lane == 0) {
+			const uint32_t v = ll - 1;
+			if (lh == 1) {
+				o[0] = (uint8_t)(v << 2);
+			} else if (lh == 2) {
+				o[0] = (uint8_t)(60 << 2);
+				o[1] = (uint8_t)v;
+			} else if (lh == 3) {
+				o[0] = (uint8_t)(61 << 2);
+				o[1] = (uint8_t)(v & 0xff);
+				o[2] = (uint8_t)(v >> 8);
+			}
+		}
+		{
+			/* literal payload: destination-aligned dwords from the input */
+			uint8_t *d = o + lh;
+			const uint32_t head = min(ll, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
+			if (lane < head)
+				d[lane] = src[ls + lane];
+			const uint32_t words = (ll - head) >> 2;
+			uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
+			for (uint32_t k = lane; k < words; k += 64) {
+				uint32_t w;
+				__builtin_memcpy(&w, src + ls + head + 4 * k, 4);
+				d32[k] = w;
+			}
+			const uint32_t t0 = head + 4 * words;
+			if (t0 + lane < ll)
+				d[t0 + lane] = src[ls + t0 + lane];
+		}
+		if (cl) {
+			uint8_t *q = o + lh + ll;
+			const uint32_t body = 3 * (k64 + k60);
+			for (uint32_t t = lane; t < cbytes; t += 64) {
+				uint8_t bb;
+				if (t < body) {
+					const uint32_t rr = t % 3;
+					bb = rr == 0 ? (t < 3 * k64 ? 0xfe : 0xee) : rr == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
+				} else {
+					const uint32_t rr = t - body;
+					const bool two = last < 12 && co < 2048;
+					bb = rr == 0 ? (two ? (uint8_t)(1 + ((last - 4) << 2) + ((co >> 8) << 5))
+							    : (uint8_t)(2 + ((last - 1) << 2)))
+					     : rr == 1 ? (uint8_t)(co & 0xff) : (uint8_t)(co >> 8);
+				}
+				q[t] = bb;
+			}
+		}
+		gpos += lh + ll + cbytes;
+		sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
+		seg_lo = e + 1;
+	}
+	drain();
+}
+
+constexpr uint32_t kEmitWaves = 4;
+constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records) */
+
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_blocks(CompressArgs A)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
+	__shared__ uint32_t chunk_tot[kMaxChunks];
+	__shared__ uint32_t chunk_base[kMaxChunks + 1];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t blk = A.blk_base + blockIdx.x;
 	const uint32_t len = A.in_len[blk];
 	const uint32_t nfr = len ? (len + kFragment - 1) / kFragment : 1;
-	if (fi >= nfr)
-		return;
-	const uint32_t hdr = A.mode == CSNAPPY_HIP_STREAM ? varint_len(len) : 0;
-	const uint32_t *fl = A.frag_len + (uint64_t)blk * A.fpb;
-	/* prefix = sum of the lengths of fragments before mine */
-	uint32_t part = 0;
-	for (uint32_t j = tid; j < fi; j += 256)
-		part += fl[j];
-	for (int d = 32; d; d >>= 1)
-		part += (uint32_t)__shfl_down((int)part, d, 64);
-	if ((tid & 63) == 0)
-		red[tid >> 6] = part;
-	__syncthreads();
-	const uint32_t prefix = red[0] + red[1] + red[2] + red[3];
-	const uint32_t mylen = fl[fi];
-	if (fi > 0) {
-		const uint8_t *s = A.scratch + (uint64_t)(blk * (uint64_t)(A.fpb - 1) + (fi - 1)) * kScratchSlot;
-		uint8_t *d = A.out + A.out_off[blk] + hdr + prefix;
-		/* head bytes until d is 4-aligned, then dwords assembled from aligned source dwords */
-		const uint32_t head = min(mylen, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
-		if (tid < head)
-			d[tid] = s[tid];
-		const uint32_t words = (mylen - head) >> 2;
-		const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s);
-		uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
-		const uint32_t sh = head & 3, sd = head >> 2;
-		for (uint32_t k = tid; k < words; k += 256)
-			d32[k] = __builtin_amdgcn_alignbyte(s32[sd + k + 1], s32[sd + k], sh);
-		const uint32_t tail = head + 4 * words;
-		if (tail + tid < mylen)
-			d[tail + tid] = s[tail + tid];
+	uint8_t *dst = A.out + A.out_off[blk];
+	uint32_t pos = 0;
+	if (A.mode == CSNAPPY_HIP_STREAM) {
+		/* encode_varint32, csnappy_compress.c:46-73 */
+		pos = varint_len(len);
+		if (tid < pos)
+			dst[tid] = (uint8_t)((len >> (7 * tid)) | (tid + 1 < pos ? 0x80u : 0u));
 	}
-	if (fi == nfr - 1 && tid == 0)
-		A.out_len[blk] = hdr + prefix + mylen;
+	for (uint32_t fi = 0; fi < nfr; ++fi) {
+		const uint32_t c = blockIdx.x * A.fpb + fi;
+		const uint32_t cnt = A.rec_cnt[c];
+		const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
+		const uint8_t *src = A.in + A.in_off[blk] + fi * kFragment;
+		const uint32_t avail = len - fi * kFragment;
+		const uint32_t nchunks = (cnt + 63) >> 6;
+		/* pass 1: encoded bytes of every 64-record chunk */
+		for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
+			const uint32_t r = ch * 64 + lane;
+			const bool live = r < cnt;
+			const RecFields f = decode_record(live ? R[r] : make_uint2(0, 0), live);
+			uint32_t total;
+			(void)wave_excl_scan(f.mine, lane, &total);
+			if (lane == 0)
+				chunk_tot[ch] = total;
+		}
+		__syncthreads();
+		if (wv == 0) {
+			/* exclusive scan of the chunk totals (<= 129 entries) */
+			uint32_t run = pos;
+			for (uint32_t b0 = 0; b0 < nchunks; b0 += 64) {
+				const uint32_t ch = b0 + lane;
+				const uint32_t v = ch < nchunks ? chunk_tot[ch] : 0;
+				uint32_t total;
+				const uint32_t ex = wave_excl_scan(v, lane, &total);
+				if (ch < nchunks)
+					chunk_base[ch] = run + ex;
+				run += total;
+			}
+			if (lane == 0)
+				chunk_base[nchunks] = run;
+		}
+		__syncthreads();
+		/* pass 2: every wave encodes its chunks at their final place */
+		for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves)
+			emit_chunk(R, ch * 64, min(64u, cnt - ch * 64), src, avail, dst + chunk_base[ch], stage_all[wv], lane);
+		pos = chunk_base[nchunks];
+		__syncthreads();
+	}
+	if (tid == 0)
+		A.out_len[blk] = pos;
 }
 
 /* ==========================================================================================
@@ -1499,65 +1557,189 @@ struct Timer {
 	}
 };
 
-constexpr uint32_t kMaxGlobalTables = 16384; /* fragments per launch in global-table mode */
-
 constexpr uint32_t kLdsPerCu = 160 * 1024;
-
-/* placement: 0 = table and window in LDS, 1 = table in global memory, 2 = table and window in
- * global memory */
-size_t compress_lds_bytes(uint32_t win_bytes, int p, int placement, uint32_t *s_entries, uint32_t *s_shift)
-{
-	uint32_t s_cap = placement ? 512u : 1024u; /* global placements: two 512-entry filters */
-	if (placement == 0) {
-		/* LDS placement: a false alarm of the filter only costs a visit of the flagged lane, one
-		 * more fragment per CU is worth more (4 KiB pages at p=13: 7 -> 8 per CU, +4 %) */
-		const size_t rest = (size_t)win_bytes + ((size_t)1 << p) + kRingBytes + kStageBytes;
-		const uint32_t full = (1u << (p - 1)) < 1024u ? (1u << (p - 1)) : 1024u;
-		const uint32_t half = full > 512u ? 512u : full;
-		if (kLdsPerCu / (rest + half * 4) > kLdsPerCu / (rest + full * 4))
-			s_cap = 512u;
-	}
-	if (const char *e = getenv("CSNAPPY_HIP_S_ENTRIES")) /* experiments */
-		s_cap = (uint32_t)atoi(e);
-	*s_entries = (1u << (p - 1)) < s_cap ? (1u << (p - 1)) : s_cap;
-	/* a second filter on the upper hash bits when one filter cannot be exact (global placements:
-	 * there every lane kept in front of the cut is two cache-line gathers, and LDS is plentiful) */
-	uint32_t bits = 0;
-	while ((1u << bits) < *s_entries)
-		++bits;
-	*s_shift = (placement != 0 && (1u << (p - 1)) > *s_entries) ? (uint32_t)(p - 1) - bits : 0;
-	if (getenv("CSNAPPY_HIP_ONE_FILTER"))
-		*s_shift = 0;
-	return (size_t)(placement == 2 ? 0 : win_bytes) + (placement ? 0 : ((size_t)1 << p)) +
-	       (size_t)*s_entries * 4 * (*s_shift ? 2 : 1) +
-	       kRingBytes + kStageBytes + (placement ? ((size_t)1 << p) >> 4 : 0);
-}
-
-/* Where the hash table and the window live.  In LDS they are one round trip closer, but a
- * 32 KiB window plus a 2^p-byte table leave room for only 1-3 fragments per CU, and the kernel
- * is bound by the latency of ONE wave's dependent chain per fragment -- so fragments in flight
- * per CU is what buys throughput.  With both in global memory (L2 / Infinity Cache resident)
- * a fragment needs ~9 KiB of LDS and 12 fit.  Measured on MI355X (tools/mode_matrix.py, G_text,
- * 64 KiB blocks, p=16): LDS 9 GiB/s, table in global 21 GiB/s, table+window in global 30 GiB/s;
- * 4 KiB pages at p=13 (7 per CU in LDS) are fastest in LDS.  So: LDS when at least four
- * fragments fit a CU that way, otherwise global.  CSNAPPY_HIP_TABLE=lds|global|gwin overrides the
- * choice (experiments). */
-int choose_placement(uint32_t win_bytes, int p)
-{
-	const char *e = getenv("CSNAPPY_HIP_TABLE");
-	if (e && !strcmp(e, "global"))
-		return 1;
-	if (e && !strcmp(e, "gwin"))
-		return 2;
-	if (e && !strcmp(e, "lds"))
-		return 0;
-	uint32_t se, sh;
-	return kLdsPerCu / compress_lds_bytes(win_bytes, p, 0, &se, &sh) < 4 ? 2 : 0;
-}
+constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
+constexpr uint32_t kDenseCapDefault = 6144; /* entries of the dense LDS table (12 KiB) */
+constexpr uint32_t kHashLdsMaxBytes = 8192; /* tables up to this size are indexed by the hash in LDS */
 
 uint32_t frags_per_block(uint32_t max_in_len)
 {
 	return max_in_len ? (max_in_len + kFragment - 1) / kFragment : 1;
+}
+
+/* longest fragment of a batch whose blocks are <= max_in_len */
+uint32_t max_fragment(uint32_t max_in_len)
+{
+	return max_in_len < kFragment ? max_in_len : kFragment;
+}
+
+/* records a fragment of <= n bytes can produce: every record but the last holds a copy of >= 4 bytes */
+uint32_t record_cap(uint32_t n)
+{
+	return n / 4 + 8;
+}
+
+/* Experiment knobs (environment, read on every batch call so that a test can switch them; each is
+ * range-checked and a bad value makes the batch call fail with CSNAPPY_HIP_E_ARG):
+ *   CSNAPPY_HIP_TABLE      auto | hash | dense | global   where the hash table lives
+ *   CSNAPPY_HIP_DENSE_CAP  256..16384 (multiple of 64)    entries of the dense LDS table
+ *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        entries per conflict filter
+ *   CSNAPPY_HIP_WGS_PER_CU 1..32                          cap on fragments in flight per CU */
+struct Knobs {
+	int table;      /* -1 auto, else TAB_* */
+	uint32_t dense_cap, s_entries, wgs_per_cu;
+	bool ok;
+};
+
+bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
+{
+	const char *e = getenv(name);
+	if (!e || !*e)
+		return true;
+	char *end = nullptr;
+	const unsigned long v = strtoul(e, &end, 10);
+	if (!end || *end || v < lo || v > hi)
+		return false;
+	*out = (uint32_t)v;
+	return true;
+}
+
+Knobs read_knobs()
+{
+	Knobs k = { -1, 0, 0, 0, true };
+	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
+		if (!strcmp(e, "hash"))
+			k.table = TAB_LDS_HASH;
+		else if (!strcmp(e, "dense"))
+			k.table = TAB_LDS_DENSE;
+		else if (!strcmp(e, "global"))
+			k.table = TAB_GLOBAL;
+		else if (strcmp(e, "auto") && *e)
+			k.ok = false;
+	}
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_DENSE_CAP", 256, 16384, &k.dense_cap) && (k.dense_cap & 63) == 0;
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_S_ENTRIES", 64, 4096, &k.s_entries) &&
+	       (k.s_entries & (k.s_entries - 1)) == 0;
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
+	return k;
+}
+
+/* Launch geometry of the parser for table power p and fragments of <= maxfrag bytes. */
+struct ParsePlan {
+	int tab;            /* TAB_* of the first launch */
+	uint32_t lds0, lds_bytes, dense_cap, s_entries, s_shift;
+	bool fallback;      /* a TAB_GLOBAL launch follows for fragments the dense table cannot hold */
+	uint32_t g_lds0, g_lds_bytes, g_s_entries, g_s_shift;
+};
+
+void filter_geometry(uint32_t slots, uint32_t s_cap, bool dense, uint32_t *s_entries, uint32_t *s_shift)
+{
+	*s_entries = slots < s_cap ? slots : s_cap;
+	if (*s_entries < 64)
+		*s_entries = 64;
+	uint32_t bits = 0;
+	while ((1u << bits) < *s_entries)
+		++bits;
+	/* a second filter on other bits of the slot when one filter cannot be exact */
+	if (slots <= *s_entries)
+		*s_shift = 0;
+	else
+		*s_shift = dense ? bits : (uint32_t)0;
+}
+
+ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
+{
+	ParsePlan P;
+	memset(&P, 0, sizeof(P));
+	const uint32_t slots = 1u << (p - 1);
+	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 512u;
+	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
+	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
+	const uint32_t most = ((maxfrag / 2 + 63) & ~63u) + 64;
+	if (!kn.dense_cap && cap > most)
+		cap = most;
+	if (cap > slots)
+		cap = slots;
+	P.tab = kn.table >= 0 ? kn.table : ((1u << p) <= kHashLdsMaxBytes ? TAB_LDS_HASH : TAB_LDS_DENSE);
+	if (P.tab == TAB_LDS_DENSE && cap >= slots)
+		P.tab = TAB_LDS_HASH; /* the dense table would be no smaller */
+	if (P.tab == TAB_LDS_HASH) {
+		P.lds0 = 1u << p;
+		filter_geometry(slots, s_cap, false, &P.s_entries, &P.s_shift);
+		if (slots > P.s_entries) {
+			uint32_t bits = 0;
+			while ((1u << bits) < P.s_entries)
+				++bits;
+			P.s_shift = (uint32_t)(p - 1) - bits;
+		}
+	} else if (P.tab == TAB_LDS_DENSE) {
+		P.dense_cap = cap;
+		const uint32_t scratch = 10u * (slots >> 5); /* prologue: two bitmaps + the prefix */
+		P.lds0 = 2 * cap > scratch ? 2 * cap : scratch;
+		P.lds0 = (P.lds0 + 15) & ~15u;
+		filter_geometry(cap, s_cap, true, &P.s_entries, &P.s_shift);
+		P.fallback = maxfrag > 3 && cap < (maxfrag - 3) / 2;
+	}
+	/* global-table geometry (first launch when forced, else the fallback) */
+	P.g_lds0 = ((1u << p) >> 4) < 16 ? 16 : (1u << p) >> 4;
+	filter_geometry(slots, s_cap, false, &P.g_s_entries, &P.g_s_shift);
+	if (slots > P.g_s_entries) {
+		uint32_t bits = 0;
+		while ((1u << bits) < P.g_s_entries)
+			++bits;
+		P.g_s_shift = (uint32_t)(p - 1) - bits;
+	}
+	P.g_lds_bytes = P.g_lds0 + P.g_s_entries * 4 * (P.g_s_shift ? 2 : 1);
+	if (P.tab == TAB_GLOBAL) {
+		P.lds0 = P.g_lds0;
+		P.s_entries = P.g_s_entries;
+		P.s_shift = P.g_s_shift;
+	}
+	P.lds_bytes = P.lds0 + P.s_entries * 4 * (P.s_shift ? 2 : 1);
+	if (kn.wgs_per_cu) {
+		/* experiments: cap the fragments per CU by padding the LDS request */
+		const uint32_t pad = (kLdsPerCu / kn.wgs_per_cu) & ~255u;
+		if (pad > P.lds_bytes)
+			P.lds_bytes = pad;
+		if (pad > P.g_lds_bytes)
+			P.g_lds_bytes = pad;
+	}
+	return P;
+}
+
+/* bytes per fragment of the `tabs` workspace region: 2-byte ids for every position, or the
+ * 2^p-byte global table (p is not known when the workspace is sized: 64 KiB) */
+uint32_t tab_stride_for(uint32_t maxfrag, const Knobs &kn)
+{
+	const uint32_t ids = ((maxfrag + 63) & ~63u) * 2;
+	const uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
+	const bool global_possible = kn.table == TAB_GLOBAL || (maxfrag > 3 && cap < (maxfrag - 3) / 2);
+	return global_possible ? 65536u : (ids < 1024 ? 1024u : ids);
+}
+
+struct Workspace {
+	uint64_t cnt_bytes, rec_bytes, tab_bytes, total;
+	uint32_t chunk_blocks, chunk_frags, rec_cap, tab_stride;
+};
+
+Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn)
+{
+	Workspace W;
+	const uint32_t fpb = frags_per_block(max_in_len);
+	uint32_t cb = kChunkFragments / fpb;
+	if (cb < 1)
+		cb = 1;
+	if (cb > nblocks)
+		cb = nblocks;
+	W.chunk_blocks = cb;
+	W.chunk_frags = cb * fpb;
+	W.rec_cap = record_cap(max_fragment(max_in_len));
+	W.tab_stride = tab_stride_for(max_fragment(max_in_len), kn);
+	W.cnt_bytes = ((uint64_t)W.chunk_frags * 4 + 255) & ~255ull;
+	W.rec_bytes = ((uint64_t)W.chunk_frags * W.rec_cap * 8 + 255) & ~255ull;
+	W.tab_bytes = (uint64_t)W.chunk_frags * W.tab_stride;
+	W.total = W.cnt_bytes + W.rec_bytes + W.tab_bytes + 65536;
+	return W;
 }
 
 } // namespace
@@ -1609,12 +1791,9 @@ void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4])
 
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len)
 {
-	const uint64_t fpb = frags_per_block(max_in_len);
-	const uint64_t fl = ((uint64_t)nblocks * fpb * sizeof(uint32_t) + 255) & ~255ull;
-	const uint64_t stagebytes = ((uint64_t)nblocks * (fpb - 1) * kScratchSlot + 65535) & ~65535ull;
-	/* global-memory hash tables (table mode "global"): one 64 KiB table per fragment in flight */
-	const uint64_t tabs = (uint64_t)nblocks * fpb < kMaxGlobalTables ? (uint64_t)nblocks * fpb : kMaxGlobalTables;
-	return (size_t)(fl + stagebytes + tabs * 65536 + 65536);
+	if (nblocks == 0)
+		return 65536;
+	return (size_t)plan_workspace(nblocks, max_in_len, read_knobs()).total;
 }
 
 int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
@@ -1626,15 +1805,19 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return CSNAPPY_HIP_E_ARG;
 	if (mode == CSNAPPY_HIP_FRAGMENT && max_in_len > kFragment)
 		return CSNAPPY_HIP_E_ARG;
+	const Knobs kn = read_knobs();
+	if (!kn.ok)
+		return CSNAPPY_HIP_E_ARG;
 	if (nblocks == 0)
 		return 0;
-	if (workspace_bytes < csnappy_hip_compress_workspace_size(nblocks, max_in_len) ||
-	    (reinterpret_cast<uintptr_t>(d_workspace) & 255))
+	const Workspace W = plan_workspace(nblocks, max_in_len, kn);
+	if (workspace_bytes < W.total || (reinterpret_cast<uintptr_t>(d_workspace) & 255))
 		return CSNAPPY_HIP_E_WORKSPACE;
 	const uint32_t fpb = frags_per_block(max_in_len);
 	if ((uint64_t)nblocks * fpb > 0x7fffffffull)
 		return CSNAPPY_HIP_E_ARG;
 	hipStream_t st = static_cast<hipStream_t>(stream);
+	const ParsePlan P = plan_parse(p, max_fragment(max_in_len), kn);
 
 	CompressArgs A;
 	A.in = static_cast<const uint8_t *>(d_in);
@@ -1643,72 +1826,66 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.out = static_cast<uint8_t *>(d_out);
 	A.out_off = d_out_off;
 	A.out_len = d_out_len;
-	A.frag_len = static_cast<uint32_t *>(d_workspace);
-	const uint64_t fl = ((uint64_t)nblocks * fpb * sizeof(uint32_t) + 255) & ~255ull;
-	A.scratch = static_cast<uint8_t *>(d_workspace) + fl;
-	A.nblocks = nblocks;
-	A.fpb = fpb;
-	A.win_bytes = ((max_in_len < kFragment ? max_in_len : kFragment) + 16 + 16 + 63) & ~63u;
-	const int placement = choose_placement(A.win_bytes, p);
-	const bool gtab = placement != 0;
-	size_t lds = compress_lds_bytes(A.win_bytes, p, placement, &A.s_entries, &A.s_shift);
-	if (const char *w = getenv("CSNAPPY_HIP_WGS_PER_CU")) {
-		/* experiments: cap the workgroups per CU by padding the LDS request */
-		const int k = atoi(w);
-		if (k > 0 && kLdsPerCu / k > lds)
-			lds = (kLdsPerCu / k) & ~(size_t)255;
+	uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+	A.rec_cnt = reinterpret_cast<uint32_t *>(ws);
+	A.recs = reinterpret_cast<uint64_t *>(ws + W.cnt_bytes);
+	{
+		/* ids / tables: 64 KiB aligned */
+		uintptr_t t = reinterpret_cast<uintptr_t>(ws + W.cnt_bytes + W.rec_bytes);
+		A.tabs = reinterpret_cast<uint8_t *>((t + 65535) & ~(uintptr_t)65535);
 	}
+	A.prof = g_prof_buf;
+	A.fpb = fpb;
+	A.rec_cap = W.rec_cap;
+	A.tab_stride = W.tab_stride;
+	A.dense_cap = P.dense_cap;
 	A.p = p;
 	A.mode = mode;
-	A.prof = g_prof_buf;
-	const uint64_t stagebytes = ((uint64_t)nblocks * (fpb - 1) * kScratchSlot + 65535) & ~65535ull;
-	{
-		/* table region: 64 KiB aligned */
-		uintptr_t t = reinterpret_cast<uintptr_t>(A.scratch) + stagebytes;
-		t = (t + 65535) & ~(uintptr_t)65535;
-		A.gtab = reinterpret_cast<uint16_t *>(t);
-	}
-	A.id_base = 0;
-	A.width = 64;
-	if (const char *w = getenv("CSNAPPY_HIP_STEP_WIDTH"))
-		A.width = (uint32_t)atoi(w);
 
 	const void *kfns[3][2] = {
-		{ reinterpret_cast<const void *>(snappy_compress_fragments),
-		  reinterpret_cast<const void *>(snappy_compress_fragments_prof) },
-		{ reinterpret_cast<const void *>(snappy_compress_fragments_gtab),
-		  reinterpret_cast<const void *>(snappy_compress_fragments_gtab_prof) },
-		{ reinterpret_cast<const void *>(snappy_compress_fragments_gwin),
-		  reinterpret_cast<const void *>(snappy_compress_fragments_gwin_prof) },
+		{ reinterpret_cast<const void *>(snappy_parse_fragments),
+		  reinterpret_cast<const void *>(snappy_parse_fragments_prof) },
+		{ reinterpret_cast<const void *>(snappy_parse_fragments_dense),
+		  reinterpret_cast<const void *>(snappy_parse_fragments_dense_prof) },
+		{ reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
+		  reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof) },
 	};
-	const void *kfn = kfns[placement][g_prof_buf ? 1 : 0];
-	if (!hip_ok(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-		    "hipFuncSetAttribute"))
+	const void *k1 = kfns[P.tab][g_prof_buf ? 1 : 0];
+	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
+	if (!hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
+		    "hipFuncSetAttribute") ||
+	    (P.fallback &&
+	     !hip_ok(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.g_lds_bytes),
+		     "hipFuncSetAttribute")))
 		return CSNAPPY_HIP_E_RUNTIME;
-	const uint32_t total = nblocks * fpb;
-	uint32_t per_launch = gtab ? kMaxGlobalTables : total;
-	if (const char *e = getenv("CSNAPPY_HIP_FRAGS_PER_LAUNCH")) {
-		const uint32_t k = (uint32_t)atoi(e); /* experiments: smaller table region */
-		if (gtab && k >= 256 && k <= kMaxGlobalTables)
-			per_launch = k;
-	}
-	Timer t(st);
-	t.start();
-	for (uint32_t base = 0; base < total; base += per_launch) {
-		const uint32_t cnt = total - base < per_launch ? total - base : per_launch;
-		A.id_base = base;
+
+	for (uint32_t b0 = 0; b0 < nblocks; b0 += W.chunk_blocks) {
+		const uint32_t nb = nblocks - b0 < W.chunk_blocks ? nblocks - b0 : W.chunk_blocks;
+		A.blk_base = b0;
 		void *args[] = { &A };
-		if (!hip_ok(hipLaunchKernel(kfn, dim3(cnt), dim3(128), args, lds, st), "launch snappy_compress_fragments"))
-			return CSNAPPY_HIP_E_RUNTIME;
-	}
-	t.stop(0);
-	if (!hip_ok(hipGetLastError(), "launch snappy_compress_fragments"))
-		return CSNAPPY_HIP_E_RUNTIME;
-	if (fpb > 1) {
+		Timer t(st);
 		t.start();
-		hipLaunchKernelGGL(snappy_stitch_blocks, dim3(nblocks * fpb), dim3(256), 0, st, A);
+		A.lds0 = P.lds0;
+		A.s_entries = P.s_entries;
+		A.s_shift = P.s_shift;
+		A.only_unparsed = 0;
+		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
+			    "launch snappy_parse_fragments"))
+			return CSNAPPY_HIP_E_RUNTIME;
+		if (P.fallback) {
+			A.lds0 = P.g_lds0;
+			A.s_entries = P.g_s_entries;
+			A.s_shift = P.g_s_shift;
+			A.only_unparsed = 1;
+			if (!hip_ok(hipLaunchKernel(k2, dim3(nb * fpb), dim3(64), args, P.g_lds_bytes, st),
+				    "launch snappy_parse_fragments_gtab"))
+				return CSNAPPY_HIP_E_RUNTIME;
+		}
+		t.stop(0);
+		t.start();
+		hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb), dim3(64 * kEmitWaves), 0, st, A);
 		t.stop(1);
-		if (!hip_ok(hipGetLastError(), "launch snappy_stitch_blocks"))
+		if (!hip_ok(hipGetLastError(), "launch snappy_emit_blocks"))
 			return CSNAPPY_HIP_E_RUNTIME;
 	}
 	return 0;

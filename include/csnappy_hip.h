@@ -91,7 +91,7 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
  * `stream` around each kernel (nothing synchronises in the launch path).
  * csnappy_hip_get_kernel_timing() waits for the recorded events, returns the summed duration
  * (milliseconds) and the number of launches per kernel since the previous read, and resets.
- * slots: [0] snappy_compress_fragments  [1] snappy_stitch_blocks  [2] snappy_decompress_blocks
+ * slots: [0] snappy_parse_fragments  [1] snappy_emit_blocks  [2] snappy_decompress_blocks
  */
 void csnappy_hip_set_kernel_timing(int enable);
 void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4]);

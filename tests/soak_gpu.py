@@ -50,7 +50,7 @@ t0, rounds, blocks_done = time.time(), 0, 0
 while time.time() - t0 < budget:
     mode = int(rng.integers(0, 2))
     p = int(rng.integers(9, 17))
-    os.environ["CSNAPPY_HIP_TABLE"] = str(rng.choice(["auto", "lds", "global", "gwin"]))
+    os.environ["CSNAPPY_HIP_TABLE"] = str(rng.choice(["auto", "hash", "dense", "global"]))
     nb = int(rng.integers(1, 300))
     top = 32768 if mode else int(rng.choice([300, 5000, 32768, 65536, 200000]))
     lens = [int(rng.choice([0, 1, 14, 15, 16, rng.integers(0, top + 1), top])) for _ in range(nb)]

@@ -111,6 +111,25 @@ def test_batch_api_rejects_bad_arguments_before_touching_the_device():
     assert L.csnappy_hip_decompress_batch(fake, fake, fake, 4, fake, fake, fake, fake, fake, 9, None) == E_ARG
     assert L.csnappy_hip_decompress_batch(fake, fake, fake, 0, fake, fake, fake, fake, fake, api.STREAM, None) == 0
     assert L.csnappy_hip_workload_generate(5, 1, 0, 1, 64, fake, None) == E_ARG
-    # workspace grows with the batch and covers one staging slot per extra fragment
-    assert L.csnappy_hip_compress_workspace_size(16384, 65536) >= 16384 * 38261
+    # workspace: 8-byte records (one per 4 input bytes at most) + 2-byte bucket ids per fragment
+    assert L.csnappy_hip_compress_workspace_size(16384, 65536) >= 32768 * (8200 * 8 + 65536)
     assert L.csnappy_hip_compress_workspace_size(16384, 4096) < L.csnappy_hip_compress_workspace_size(16384, 65536)
+    # a batch is parsed in chunks of 32768 fragments: the workspace stops growing there
+    assert L.csnappy_hip_compress_workspace_size(1 << 20, 65536) == L.csnappy_hip_compress_workspace_size(16384, 65536)
+
+
+@pytest.mark.parametrize("name,value", [
+    ("CSNAPPY_HIP_S_ENTRIES", "0"), ("CSNAPPY_HIP_S_ENTRIES", "48"), ("CSNAPPY_HIP_S_ENTRIES", "8192"),
+    ("CSNAPPY_HIP_DENSE_CAP", "0"), ("CSNAPPY_HIP_DENSE_CAP", "100"), ("CSNAPPY_HIP_DENSE_CAP", "99999"),
+    ("CSNAPPY_HIP_WGS_PER_CU", "0"), ("CSNAPPY_HIP_WGS_PER_CU", "x"), ("CSNAPPY_HIP_TABLE", "nonsense"),
+])
+def test_experiment_knobs_are_range_checked(name, value, monkeypatch):
+    """The CSNAPPY_HIP_* environment knobs exist for experiments; a value outside its range makes
+    the batch call fail with CSNAPPY_HIP_E_ARG instead of reaching a kernel."""
+    L = api.lib()
+    fake = 0x10000
+    ws = L.csnappy_hip_compress_workspace_size(4, 65536)
+    call = lambda: L.csnappy_hip_compress_batch(fake, fake, fake, 4, 65536, fake, fake, fake, 16, api.STREAM,
+                                                fake, ws, None)
+    monkeypatch.setenv(name, value)
+    assert call() == -101

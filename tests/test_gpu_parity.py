@@ -411,11 +411,25 @@ def test_cl_tester_round_trip_and_selftests(torch, urls, golden_dir, tmp_path):
     assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)
 
 
-@pytest.mark.parametrize("placement", ["lds", "global", "gwin"])
+PLACEMENTS = ["hash", "dense", "global", "dense-cap256"]
+
+
+def _force_placement(monkeypatch, placement):
+    """hash / dense / global: where the parser keeps its table.  dense-cap256: a dense LDS table so
+    small that most fragments overflow it and take the second (global-table) launch."""
+    if placement == "dense-cap256":
+        monkeypatch.setenv("CSNAPPY_HIP_TABLE", "dense")
+        monkeypatch.setenv("CSNAPPY_HIP_DENSE_CAP", "256")
+    else:
+        monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+
+
+@pytest.mark.parametrize("placement", PLACEMENTS)
 def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
-    """The compress kernel has three instantiations (hash table / window in LDS or in global
-    memory); the library picks one by LDS occupancy.  Force each and check the same bytes."""
-    monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+    """The parser has three instantiations (table indexed by the hash in LDS, by dense bucket ids
+    in LDS, or the full table in global memory); the library picks by table size and hands
+    fragments that overflow the dense table to the global one.  Force each and check the bytes."""
+    _force_placement(monkeypatch, placement)
     xs = list(_ragged_cases(900, 40))
     host = np.concatenate(xs)
     lens = [len(x) for x in xs]
@@ -458,11 +472,11 @@ def _slot_sharing_cases(seed, count):
         yield x
 
 
-@pytest.mark.parametrize("placement", ["lds", "global", "gwin"])
+@pytest.mark.parametrize("placement", PLACEMENTS)
 def test_slot_sharing_inside_a_step_is_resolved_exactly(torch, chk, placement, monkeypatch):
     """Dense steps forward a flagged lane's candidate from an earlier lane of the same step (or cut
-    the step in the global placements): every placement, several table powers, both modes."""
-    monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+    the step in the global placement): every placement, several table powers, both modes."""
+    _force_placement(monkeypatch, placement)
     xs = list(_slot_sharing_cases(77, 60))
     for p, mode in ((16, api.STREAM), (12, api.STREAM), (9, api.STREAM), (13, api.FRAGMENT)):
         ys = [x[:32768] for x in xs] if mode == api.FRAGMENT else xs

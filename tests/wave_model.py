@@ -1,6 +1,6 @@
 """Lane-level model of the compress kernel's step logic (TEST INFRASTRUCTURE).
 
-`snappy_compress_fragments` (csnappy_amd/csrc/csnappy_kernels.hip) evaluates 64 positions of the
+`snappy_parse_fragments` (csnappy_amd/csrc/csnappy_kernels.hip) evaluates 64 positions of the
 reference's sequential probe loop per step and truncates the step at the first lane that shares
 a hash slot with an earlier lane.  This file restates that step logic in plain Python, lane by
 lane, so the claim "the wave-step algorithm is bit-identical to the sequential loop of

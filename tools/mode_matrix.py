@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Compress/decompress kernel time per workload x table mode x table power (run on the GPU box)."""
+"""Compress/decompress kernel time per workload x table mode x table power (run on the GPU box).
+usage: mode_matrix.py [workload:p,p,..]...   (default: the round-2 sweep)"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows = []
-for wl, ps in (("text", (16, 15, 14)), ("urls", (16, 15)), ("low", (16,)), ("page", (13,))):
-    for p in ps:
-        for mode in ("lds", "global", "gwin"):
+spec = sys.argv[1:] or ["text:16,15,14,13,12", "urls:16,14", "low:16", "page:13"]
+for item in spec:
+    wl, ps = item.split(":")
+    for p in (int(x) for x in ps.split(",")):
+        for mode in ("hash", "dense", "global"):
             env = dict(os.environ, CSNAPPY_HIP_TABLE=mode)
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                                   "--no-cpu-baseline", "--workload", wl, "--p", str(p), "--gib", "0.5"],

@@ -27,7 +27,7 @@ summary = {"bench_args": args, "kernels": {}, "pmc": {}, "per_batch": {}}
 
 def family(name):
     """compress runs as one or more chunk launches of one of its instantiations per batch call"""
-    return "snappy_compress_fragments" if name.startswith("snappy_compress_fragments") else name
+    return "snappy_parse_fragments" if name.startswith("snappy_parse_fragments") else name
 for r in rows("stats/**/*kernel_stats.csv"):
     name = r.get("Name", "")
     if "snappy" in name or "workload" in name:
