@@ -68,6 +68,7 @@ struct CompressArgs {
 	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
 	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
 	uint32_t only_unparsed; /* TAB_GLOBAL: skip fragments that already have records */
+	uint32_t sample_min;    /* TAB_LDS_DENSE: full fragments with fewer distinct sampled hashes go to TAB_GLOBAL */
 	int p;
 	int mode;
 };
@@ -88,6 +89,21 @@ struct DecompressArgs {
 DEVINL uint32_t rdlane(uint32_t v, uint32_t l)
 {
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
+/* number of equal leading bytes (0..16) of two 16-byte strings given as the XOR of their halves;
+ * branch-free (a lane-divergent branch here would sit next to the joins of the parser's cursor
+ * state and drag it off the scalar unit) */
+DEVINL uint32_t common_prefix16(uint64_t xlo, uint64_t xhi)
+{
+	const uint32_t zl = (uint32_t)__ffsll((unsigned long long)xlo), zh = (uint32_t)__ffsll((unsigned long long)xhi);
+	return zl ? (zl - 1) >> 3 : zh ? 8u + ((zh - 1) >> 3) : 16u;
+}
+
+/* a value that is the same in every lane, as a scalar */
+DEVINL uint32_t uni(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 DEVINL uint32_t first_lane(uint64_t m)
@@ -137,13 +153,11 @@ DEVINL uint32_t scan_pos(uint32_t s, uint32_t i)
 /* Table power csnappy_compress uses for a fragment of n bytes (csnappy_compress.c:638-646). */
 DEVINL int fragment_power(uint32_t n, int p, int mode)
 {
-	int ws = p;
-	if (mode == CSNAPPY_HIP_STREAM && n < kFragment) {
-		for (ws = 9; ws < p; ++ws)
-			if ((1u << (ws - 1)) >= n)
-				break;
-	}
-	return ws;
+	/* short last fragment of a stream: the smallest ws in 9..p with 2^(ws-1) >= n */
+	if (mode != CSNAPPY_HIP_STREAM || n >= kFragment || n <= 256)
+		return (mode == CSNAPPY_HIP_STREAM && n <= 256) ? 9 : p;
+	const int ws = 33 - __builtin_clz(n - 1);
+	return ws < p ? ws : p;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -215,6 +229,7 @@ constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
 constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging */
 constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu; /* rec_cnt: "not parsed yet, needs the global-table parser" */
+constexpr bool kTouchAhead = true;          /* parser: touch the input / id lines of the step after next */
 constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
 
 enum { TAB_LDS_HASH = 0, TAB_LDS_DENSE = 1, TAB_GLOBAL = 2 };
@@ -269,6 +284,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t0 = 0, t1 = 0;
 	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
 	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0, t_pre = 0, t_loop_end = 0;
+	unsigned long long tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
+	unsigned long long n_hops = 0, n_flagv = 0, n_fwd = 0, n_flagged = 0;
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
 
@@ -278,6 +295,33 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			 * seen1/seen2: slot hit at least once / at least twice; pref: buckets below a word */
 			const uint32_t nwords = (1u << (ws - 1)) >> 5; /* >= 8 */
 			uint32_t *seen1 = reinterpret_cast<uint32_t *>(smem), *seen2 = seen1 + nwords;
+			if (A.sample_min && n == kFragment) {
+				/* Placement by a cheap look at the data (a speed heuristic, the bytes do not depend
+				 * on it): fragments made of long runs need few steps, and the fixed cost of this
+				 * prologue would be most of their time -- the global-table launch (no prologue,
+				 * more fragments per CU) is faster for them.  Hash every 16th position into an
+				 * 8192-bit map; few distinct values = repetitive. */
+				for (uint32_t k = lane; k < 256; k += 64)
+					seen1[k] = 0;
+				wave_lds_fence();
+				for (uint32_t j = 0; j < 32; ++j) {
+					uint32_t w;
+					__builtin_memcpy(&w, src + 16 * lane + 1024 * j, 4);
+					const uint32_t h = (w * kHashMul) >> 19;
+					atomicOr(&seen1[h >> 5], 1u << (h & 31));
+				}
+				wave_lds_fence();
+				uint32_t d = 0, distinct;
+				for (uint32_t k = 0; k < 4; ++k)
+					d += (uint32_t)__builtin_popcount(seen1[lane * 4 + k]);
+				(void)wave_excl_scan(d, lane, &distinct);
+				wave_lds_fence();
+				if (distinct < A.sample_min) {
+					if (lane == 0)
+						A.rec_cnt[c] = kNoRecords;
+					return;
+				}
+			}
 			uint16_t *pref = reinterpret_cast<uint16_t *>(seen2 + nwords);
 			for (uint32_t k = lane; k < 2 * nwords; k += 64)
 				seen1[k] = 0;
@@ -308,26 +352,43 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				hh[6] = (__builtin_amdgcn_alignbyte(w2, w1, 2) * kHashMul) >> shift;
 				hh[7] = (__builtin_amdgcn_alignbyte(w2, w1, 3) * kHashMul) >> shift;
 			};
-			{
-				uint4 nxt = load16(8 * lane);
-				for (uint32_t b0 = 0; b0 < npos; b0 += 512) {
-					const uint32_t i = b0 + 8 * lane;
-					const uint32_t cntp = i < npos ? min(8u, npos - i) : 0;
-					const uint4 v = nxt;
-					if (b0 + 512 < npos)
-						nxt = load16(i + 512);
-					uint32_t hh[8], old[8];
-					hash8(v, hh);
+			/* a sweep over all positions: 2048 per iteration (four 16-byte loads per lane in flight,
+			 * the next iteration's requested before this one's are used) */
+			auto sweep = [&](auto &&body) {
+				uint4 nxt[4];
 #pragma unroll
-					for (uint32_t k = 0; k < 8; ++k)
-						old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+				for (uint32_t j = 0; j < 4; ++j)
+					nxt[j] = load16(512 * j + 8 * lane);
+				for (uint32_t b0 = 0; b0 < npos; b0 += 2048) {
+					uint4 cur[4];
 #pragma unroll
-					for (uint32_t k = 0; k < 8; ++k)
-						if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
-							atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
+					for (uint32_t j = 0; j < 4; ++j) {
+						cur[j] = nxt[j];
+						if (b0 + 2048 < npos)
+							nxt[j] = load16(b0 + 2048 + 512 * j + 8 * lane);
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j) {
+						const uint32_t i = b0 + 512 * j + 8 * lane;
+						if (b0 + 512 * j < npos)
+							body(cur[j], i, i < npos ? min(8u, npos - i) : 0u);
+					}
 				}
-			}
+			};
+			sweep([&](const uint4 &v, uint32_t, uint32_t cntp) {
+				uint32_t hh[8], old[8];
+				hash8(v, hh);
+#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k)
+					old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k)
+					if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
+						atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
+			});
 			wave_lds_fence();
+			if (PROF)
+				tp1 = __builtin_amdgcn_s_memtime();
 			const uint32_t per = max(1u, nwords >> 6);
 			uint32_t mine = 0;
 			for (uint32_t k = 0; k < per; ++k) {
@@ -351,39 +412,37 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				}
 			}
 			wave_lds_fence();
+			if (PROF)
+				tp2 = __builtin_amdgcn_s_memtime();
 			uint16_t *wids = reinterpret_cast<uint16_t *>(region);
-			{
-				uint4 nxt = load16(8 * lane);
-				for (uint32_t b0 = 0; b0 < npos; b0 += 512) {
-					const uint32_t i = b0 + 8 * lane;
-					const uint32_t cntp = i < npos ? min(8u, npos - i) : 0;
-					const uint4 v = nxt;
-					if (b0 + 512 < npos)
-						nxt = load16(i + 512);
-					uint32_t hh[8], id[8];
-					hash8(v, hh);
+			sweep([&](const uint4 &v, uint32_t i, uint32_t cntp) {
+				uint32_t hh[8], id[8];
+				hash8(v, hh);
 #pragma unroll
-					for (uint32_t k = 0; k < 8; ++k) {
-						const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
-						const uint32_t b = 1u << (hh[k] & 31);
-						id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
-					}
-					if (cntp == 8) {
-						*reinterpret_cast<uint4 *>(wids + i) =
-							make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
-								   id[6] | (id[7] << 16));
-					} else {
-#pragma unroll
-						for (uint32_t k = 0; k < 7; ++k)
-							if (k < cntp)
-								wids[i + k] = (uint16_t)id[k];
-					}
+				for (uint32_t k = 0; k < 8; ++k) {
+					const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
+					const uint32_t b = 1u << (hh[k] & 31);
+					id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
 				}
-			}
+				if (cntp == 8) {
+					*reinterpret_cast<uint4 *>(wids + i) =
+						make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
+							   id[6] | (id[7] << 16));
+				} else {
+#pragma unroll
+					for (uint32_t k = 0; k < 7; ++k)
+						if (k < cntp)
+							wids[i + k] = (uint16_t)id[k];
+				}
+			});
 			wave_lds_fence();
 			/* the ids are read back by this wave only (same CU, same L1/L2 path, program order);
 			 * make the stores leave the wave before the first load of them is issued */
+			if (PROF)
+				tp3 = __builtin_amdgcn_s_memtime();
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (PROF)
+				tp4 = __builtin_amdgcn_s_memtime();
 		}
 		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
 		{
@@ -418,20 +477,16 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			uint32_t m8 = 0;
 			bool term = true;
 			if (o < lim) {
-				if (o + 8 > lim) {
-					/* the last few bytes of the fragment: never read past the input */
-					while (m8 < lim - o && src[ma + o + m8] == src[mb + o + m8])
-						++m8;
-					term = true;
-				} else {
-					uint64_t xa, xb;
-					__builtin_memcpy(&xa, src + ma + o, 8);
-					__builtin_memcpy(&xb, src + mb + o, 8);
-					const uint64_t x = xa ^ xb;
-					m8 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-					m8 = min(m8, lim - o);
-					term = m8 < 8 || o + 8 >= lim;
-				}
+				/* the last few bytes of the fragment: never read past the input -- take the eight
+				 * bytes that END at the fragment's end and drop the ones in front of o */
+				const uint32_t r = min(8u, lim - o), back = 8 - r;
+				uint64_t xa, xb;
+				__builtin_memcpy(&xa, src + ma + o - back, 8);
+				__builtin_memcpy(&xb, src + mb + o - back, 8);
+				const uint64_t x = (xa ^ xb) >> (8 * back);
+				const uint32_t z = (uint32_t)__ffsll((unsigned long long)x); /* 0 when x == 0 */
+				m8 = z ? min((z - 1) >> 3, r) : r;
+				term = m8 < 8 || o + 8 >= lim;
 			}
 			const uint64_t tmask = __ballot(term);
 			if (tmask) {
@@ -442,7 +497,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 		}
 	};
 
-	if (n >= kMargin) {
+	/* (a 15-byte fragment has ip_limit 0: no probe ever happens, it is one literal like n < 15) */
+	if (n > kMargin) {
 		const uint32_t ip_limit = n - kMargin;
 		uint32_t ip = 0;        /* position right after the last copy (spec > 0) */
 		uint32_t spec = 0;      /* leading special lanes: 2 = {insert ip-1, probe ip}, 1 = {probe ip} */
@@ -460,6 +516,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 		uint32_t p0, pos;
 		bool valid;
 		uint32_t raw[4], sid = kNoBucket;
+		uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
 		auto place = [&]() {
 			sparse = spec == 0 && qi >= 32;
 			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
@@ -474,20 +531,30 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			}
 			if (!valid)
 				pos = 0;
-			/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others must
-			 * not read at all: the input may end right behind a 15-byte fragment */
-			uint4 v = make_uint4(0, 0, 0, 0);
-			uint16_t idv = (uint16_t)kNoBucket;
-			if (valid) {
-				__builtin_memcpy(&v, src + pos, 16);
-				if (DENSE)
-					idv = ids[pos];
-			}
+			/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others read position
+			 * 0 (n >= 16 here).  No branch on `valid`: a lane-divergent branch next to the joins of
+			 * the cursor state makes the compiler treat that state as divergent and the whole
+			 * chain walk leaves the scalar unit */
+			uint4 v;
+			__builtin_memcpy(&v, src + pos, 16);
+			const uint16_t idv = DENSE ? ids[pos] : (uint16_t)kNoBucket;
 			raw[0] = v.x;
 			raw[1] = v.y;
 			raw[2] = v.z;
 			raw[3] = v.w;
 			sid = idv;
+			/* touch what the step after this one will read (the cursor moves ~64 positions per
+			 * step), so that its loads find the lines in the cache; the values are not used */
+			asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
+			if (kTouchAhead && !sparse) {
+				const uint32_t q0 = min(pos + 64, n - 4), q1 = min(pos + 128, n - 4);
+				__builtin_memcpy(&pf0, src + q0, 4);
+				__builtin_memcpy(&pf1, src + q1, 4);
+				if (DENSE) {
+					pf2 = ids[q0];
+					pf3 = ids[q1];
+				}
+			}
 		};
 		place();
 		if (PROF)
@@ -500,6 +567,16 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				if (sparse)
 					n_sparse++;
 			}
+			/* the cursor state is the same in every lane: say so (keeps the chain walk on the
+			 * scalar unit) */
+			ip = uni(ip);
+			spec = uni(spec);
+			s = uni(s);
+			qi = uni(qi);
+			next_emit = uni(next_emit);
+			nev = uni(nev);
+			p0 = uni(p0);
+			sparse = uni((uint32_t)sparse) != 0;
 			/* this step's lane state (the next step's is placed before the step ends) */
 			const bool sparse_c = sparse;
 			const uint32_t p0_c = p0, pos_c = pos;
@@ -563,8 +640,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			 * 16 bytes away from every valid probe position) */
 			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
 			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
-			uint32_t mlen = xlo ? (uint32_t)(__builtin_ctzll(xlo) >> 3)
-				      : xhi ? 8u + (uint32_t)(__builtin_ctzll(xhi) >> 3) : 16u;
+			uint32_t mlen = common_prefix16(xlo, xhi);
 			if (!maybe || (GTAB && flagged))
 				mlen = 0; /* (nothing was gathered for a flagged lane of the global placement) */
 			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
@@ -619,6 +695,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				/* flagged lanes are stops of the chain like matches: what they hold is decided
 				 * when (and if) the chain gets there */
 				const uint64_t flagmask = ulim < 64 ? cmask & ((1ull << ulim) - 1) : cmask;
+				if (PROF)
+					n_flagged += __builtin_popcountll(flagmask);
 				const uint64_t stopmask = matchmask | flagmask;
 				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
 				const uint64_t special = widemask | flagmask; /* stops that are not plain matches */
@@ -667,9 +745,12 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 					bool sp = (special >> i) & 1;
 					for (;;) {
 						uint32_t t;
+						i = (int)uni((uint32_t)i);
 						if (sp) {
 							uint32_t L = kLocalMatch;
 							if ((flagmask >> i) & 1) {
+								if (PROF)
+									n_flagv++;
 								/* ---- the chain probes a flagged lane ----
 								 * Its candidate is the latest position inserted for its slot: the
 								 * highest lane below it that this step inserts (not strictly inside a
@@ -680,15 +761,17 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
 								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
 								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(below != 0 && lane + 1 < cprev);
-								const uint64_t same = __ballot(tabbed && slot == rdlane(slot, i)) & ins;
+								const uint32_t slot_i = rdlane(slot, i);
+								const uint64_t same = __ballot(tabbed & (slot == slot_i)) & ins;
 								if (same) {
+									if (PROF)
+										n_fwd++;
 									const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
 									const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
 									const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
 									const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
 									const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
-									const uint32_t ml = ylo ? (uint32_t)(__builtin_ctzll(ylo) >> 3)
-											: yhi ? 8u + (uint32_t)(__builtin_ctzll(yhi) >> 3) : 16u;
+									const uint32_t ml = common_prefix16(ylo, yhi);
 									L = rdlane(ml, i);
 									if ((int)lane == i) {
 										cand = p0_c + j;
@@ -737,6 +820,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 						} else {
 							/* plain matches: hop from match to match */
 							for (;;) {
+								if (PROF)
+									n_hops++;
 								taken |= 1ull << i;
 								last = i;
 								t = rdlane(nx, i);
@@ -905,6 +990,14 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 		atomicAdd(&A.prof[13], t_rec);
 		atomicAdd(&A.prof[14], t_pre);
 		atomicAdd(&A.prof[15], t_end - t_loop_end);
+		atomicAdd(&A.prof[16], tp1 - t_begin);
+		atomicAdd(&A.prof[17], tp2 - tp1);
+		atomicAdd(&A.prof[18], tp3 - tp2);
+		atomicAdd(&A.prof[19], tp4 - tp3);
+		atomicAdd(&A.prof[20], n_hops);
+		atomicAdd(&A.prof[21], n_flagv);
+		atomicAdd(&A.prof[22], n_fwd);
+		atomicAdd(&A.prof[23], n_flagged);
 	}
 }
 
@@ -1010,24 +1103,20 @@ DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8
 	const uint32_t lit_start = f.lit_start, lit_len = f.lit_len, coff = f.coff, clen = f.clen;
 	const uint32_t lhdr = f.lhdr, mine = f.mine;
 	const CopyPlan cp = f.cp;
-	uint64_t bigmask = __ballot(mine > kBigRecord);
+	/* small records are staged in LDS, their literal (< 32 bytes) fetched with two 16-byte loads;
+	 * a record is "big" when it encodes to more than kBigRecord bytes -- or when those 32 bytes
+	 * would reach past the end of the block's input: big records go straight to HBM */
+	const bool small = live && mine <= kBigRecord && (lit_len == 0 || lit_start + 32 <= avail);
+	uint64_t bigmask = __ballot(live && !small);
 	uint32_t total;
 	const uint32_t excl = wave_excl_scan(mine, lane, &total);
-	/* literal payload of a small record (< 32 bytes): two 16 B loads, taken before any staging */
 	uint32_t lw[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	if (live && mine <= kBigRecord && lit_len) {
-		if (lit_start + 32 <= avail) {
-			uint4 a, b;
-			__builtin_memcpy(&a, src + lit_start, 16);
-			__builtin_memcpy(&b, src + lit_start + 16, 16);
-			lw[0] = a.x; lw[1] = a.y; lw[2] = a.z; lw[3] = a.w;
-			lw[4] = b.x; lw[5] = b.y; lw[6] = b.z; lw[7] = b.w;
-		} else {
-#pragma unroll
-			for (uint32_t k = 0; k < 32; ++k)
-				if (k < lit_len)
-					lw[k >> 2] |= (uint32_t)src[lit_start + k] << (8 * (k & 3));
-		}
+	if (small && lit_len) {
+		uint4 a, b;
+		__builtin_memcpy(&a, src + lit_start, 16);
+		__builtin_memcpy(&b, src + lit_start + 16, 16);
+		lw[0] = a.x; lw[1] = a.y; lw[2] = a.z; lw[3] = a.w;
+		lw[4] = b.x; lw[5] = b.y; lw[6] = b.z; lw[7] = b.w;
 	}
 	uint32_t seg_lo = 0; /* first record of the current run of small records */
 	while (nev) {
@@ -1559,7 +1648,8 @@ struct Timer {
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
-constexpr uint32_t kDenseCapDefault = 6144; /* entries of the dense LDS table (12 KiB) */
+constexpr uint32_t kDenseCapDefault = 5632; /* entries of the dense LDS table (11 KiB): URL-like text has 4.5-5.5 k buckets per fragment */
+constexpr uint32_t kSampleMinDefault = 700; /* of 2048 sampled positions (text: ~1400, runs: ~300) */
 constexpr uint32_t kHashLdsMaxBytes = 8192; /* tables up to this size are indexed by the hash in LDS */
 
 uint32_t frags_per_block(uint32_t max_in_len)
@@ -1584,10 +1674,12 @@ uint32_t record_cap(uint32_t n)
  *   CSNAPPY_HIP_TABLE      auto | hash | dense | global   where the hash table lives
  *   CSNAPPY_HIP_DENSE_CAP  256..16384 (multiple of 64)    entries of the dense LDS table
  *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        entries per conflict filter
- *   CSNAPPY_HIP_WGS_PER_CU 1..32                          cap on fragments in flight per CU */
+ *   CSNAPPY_HIP_WGS_PER_CU 1..32                          cap on fragments in flight per CU
+ *   CSNAPPY_HIP_SAMPLE_MIN 0..2048                        dense placement: sampled-distinct threshold
+ *                                                         below which a fragment takes the global table */
 struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
-	uint32_t dense_cap, s_entries, wgs_per_cu;
+	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min;
 	bool ok;
 };
 
@@ -1606,7 +1698,7 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, true };
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, true };
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -1621,6 +1713,7 @@ Knobs read_knobs()
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_S_ENTRIES", 64, 4096, &k.s_entries) &&
 	       (k.s_entries & (k.s_entries - 1)) == 0;
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_SAMPLE_MIN", 0, 2048, &k.sample_min);
 	return k;
 }
 
@@ -1628,6 +1721,7 @@ Knobs read_knobs()
 struct ParsePlan {
 	int tab;            /* TAB_* of the first launch */
 	uint32_t lds0, lds_bytes, dense_cap, s_entries, s_shift;
+	uint32_t sample_min;
 	bool fallback;      /* a TAB_GLOBAL launch follows for fragments the dense table cannot hold */
 	uint32_t g_lds0, g_lds_bytes, g_s_entries, g_s_shift;
 };
@@ -1652,7 +1746,9 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	ParsePlan P;
 	memset(&P, 0, sizeof(P));
 	const uint32_t slots = 1u << (p - 1);
-	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 512u;
+	/* two 256-entry filters: a false alarm only costs a visit of the flagged lane when the chain
+	 * gets there (0.3 visits per step on text), LDS buys fragments per CU */
+	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 256u;
 	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
 	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
 	const uint32_t most = ((maxfrag / 2 + 63) & ~63u) + 64;
@@ -1678,7 +1774,8 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		P.lds0 = 2 * cap > scratch ? 2 * cap : scratch;
 		P.lds0 = (P.lds0 + 15) & ~15u;
 		filter_geometry(cap, s_cap, true, &P.s_entries, &P.s_shift);
-		P.fallback = maxfrag > 3 && cap < (maxfrag - 3) / 2;
+		P.fallback = (maxfrag > 3 && cap < (maxfrag - 3) / 2) || (kn.sample_min && maxfrag == kFragment);
+		P.sample_min = kn.sample_min;
 	}
 	/* global-table geometry (first launch when forced, else the fallback) */
 	P.g_lds0 = ((1u << p) >> 4) < 16 ? 16 : (1u << p) >> 4;
@@ -1713,7 +1810,8 @@ uint32_t tab_stride_for(uint32_t maxfrag, const Knobs &kn)
 {
 	const uint32_t ids = ((maxfrag + 63) & ~63u) * 2;
 	const uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
-	const bool global_possible = kn.table == TAB_GLOBAL || (maxfrag > 3 && cap < (maxfrag - 3) / 2);
+	const bool global_possible = kn.table == TAB_GLOBAL || (maxfrag > 3 && cap < (maxfrag - 3) / 2) ||
+				     (kn.sample_min && maxfrag == kFragment);
 	return global_possible ? 65536u : (ids < 1024 ? 1024u : ids);
 }
 
@@ -1759,7 +1857,7 @@ const char *csnappy_hip_last_error(void)
 	return g_last_error;
 }
 
-/* debug only (not in the public header): 16 x u64 device buffer that receives the parser's
+/* debug only (not in the public header): 24 x u64 device buffer that receives the parser's
  * s_memtime phase counters; NULL switches back to the production kernel */
 void csnappy_hip_debug_set_profile_buffer(void *d_buf)
 {
@@ -1839,6 +1937,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.rec_cap = W.rec_cap;
 	A.tab_stride = W.tab_stride;
 	A.dense_cap = P.dense_cap;
+	A.sample_min = P.sample_min;
 	A.p = p;
 	A.mode = mode;
 

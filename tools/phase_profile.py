@@ -22,7 +22,7 @@ else:
     d_in = torch.from_numpy(np.resize(raw, nb * block)).cuda()
 b = api.Batch([block] * nb)
 d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
-prof = torch.zeros(16, dtype=torch.int64, device="cuda")
+prof = torch.zeros(24, dtype=torch.int64, device="cuda")
 L = api.lib()
 L.csnappy_hip_debug_set_profile_buffer.argtypes = [C.c_void_p]
 for it in range(2):
@@ -38,5 +38,5 @@ print("table mode:", os.environ.get("CSNAPPY_HIP_TABLE", "auto (by LDS occupancy
 print(f"fragments {nf}  steps/frag {v[5]/nf:.1f}  matches/frag {v[6]/nf:.1f}  wide/frag {v[7]/nf:.1f}  sparse/frag {v[8]/nf:.1f}")
 for i, n in enumerate(names):
     print(f"  {n:8s} {v[i]/nf:12.0f} ticks/frag   {v[i]/max(v[5],1):9.1f} per step   {v[i]/max(v[6],1):9.1f} per match")
-for i, n in ((10, "w.chain"), (11, "w.stop"), (12, "w.place"), (13, "w.records"), (14, "pre-loop"), (15, "post-loop")):
+for i, n in ((10, "w.chain"), (11, "w.stop"), (12, "w.place"), (13, "w.records"), (14, "pre-loop"), (15, "post-loop"), (16, "pro.count"), (17, "pro.prefix"), (18, "pro.ids"), (19, "pro.fence"), (20, "n.hops"), (21, "n.flag_visits"), (22, "n.flag_forwarded"), (23, "n.flagged_lanes")):
     print(f"  {n:9s} {v[i]/nf:11.0f} ticks/frag   {v[i]/max(v[5],1):9.1f} per step")
