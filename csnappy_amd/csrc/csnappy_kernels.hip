@@ -68,6 +68,7 @@ struct CompressArgs {
 	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
 	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
 	uint32_t only_unparsed; /* TAB_GLOBAL: skip fragments that already have records */
+	uint32_t emit_wave_per_block, emit_blocks; /* emit: one wave per block (fpb == 1, small blocks) */
 	uint32_t sample_min;    /* TAB_LDS_DENSE: full fragments with fewer distinct sampled hashes go to TAB_GLOBAL */
 	int p;
 	int mode;
@@ -1065,8 +1066,41 @@ DEVINL RecFields decode_record(uint2 r, bool live)
 
 /* encode records [first, first + nev) of one fragment to dst (their final place); src = the
  * fragment's input, avail = input bytes readable from src (to the end of the block) */
-DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8_t *src, uint32_t avail,
-		       uint8_t *dst, uint8_t *stage, uint32_t lane)
+/* what emit_chunk needs from memory for one chunk, fetched one chunk ahead of its use */
+struct ChunkIn {
+	uint2 r;     /* the lane's record */
+	uint4 la, lb; /* 32 bytes at the record's literal (small records only) */
+};
+
+DEVINL bool record_is_small(const RecFields &f, bool live, uint32_t avail)
+{
+	/* small records are staged in LDS, their literal (< 32 bytes) fetched with two 16-byte loads;
+	 * a record is "big" when it encodes to more than kBigRecord bytes -- or when those 32 bytes
+	 * would reach past the end of the block's input: big records go straight to HBM */
+	return live && f.mine <= kBigRecord && (f.lit_len == 0 || f.lit_start + 32 <= avail);
+}
+
+DEVINL uint2 fetch_record(const uint2 *R, uint32_t first, uint32_t nev, uint32_t lane)
+{
+	return lane < nev ? R[first + lane] : make_uint2(0, 0);
+}
+
+DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t avail, uint32_t lane)
+{
+	const bool live = lane < nev;
+	const RecFields f = decode_record(c.r, live);
+	c.la = c.lb = make_uint4(0, 0, 0, 0);
+	if (record_is_small(f, live, avail) && f.lit_len) {
+		__builtin_memcpy(&c.la, src + f.lit_start, 16);
+		__builtin_memcpy(&c.lb, src + f.lit_start + 16, 16);
+	}
+}
+
+/* `ahead` = the loads already issued for the wave's next chunk: they are waited for in front of
+ * this chunk's stores (gfx9 has one counter for loads and stores; a wait behind the stores would
+ * also sit out their round trip) */
+DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, const uint8_t *src, uint32_t avail,
+			   uint8_t *dst, uint8_t *stage, uint32_t lane)
 {
 	/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
 	 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
@@ -1075,6 +1109,8 @@ DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8
 
 	auto drain = [&]() {
 		wave_lds_fence();
+		asm volatile("" : "+v"(ahead.r.x), "+v"(ahead.r.y), "+v"(ahead.la.x), "+v"(ahead.la.y), "+v"(ahead.la.z),
+			     "+v"(ahead.la.w), "+v"(ahead.lb.x), "+v"(ahead.lb.y), "+v"(ahead.lb.z), "+v"(ahead.lb.w));
 		uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
 		const uint32_t end = sa + fill;
 		uint32_t first_full = 0;
@@ -1098,26 +1134,15 @@ DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8
 	};
 
 	const bool live = lane < nev;
-	const uint2 r = live ? R[first + lane] : make_uint2(0, 0);
-	const RecFields f = decode_record(r, live);
+	const RecFields f = decode_record(in.r, live);
 	const uint32_t lit_start = f.lit_start, lit_len = f.lit_len, coff = f.coff, clen = f.clen;
 	const uint32_t lhdr = f.lhdr, mine = f.mine;
 	const CopyPlan cp = f.cp;
-	/* small records are staged in LDS, their literal (< 32 bytes) fetched with two 16-byte loads;
-	 * a record is "big" when it encodes to more than kBigRecord bytes -- or when those 32 bytes
-	 * would reach past the end of the block's input: big records go straight to HBM */
-	const bool small = live && mine <= kBigRecord && (lit_len == 0 || lit_start + 32 <= avail);
+	const bool small = record_is_small(f, live, avail);
 	uint64_t bigmask = __ballot(live && !small);
 	uint32_t total;
 	const uint32_t excl = wave_excl_scan(mine, lane, &total);
-	uint32_t lw[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	if (small && lit_len) {
-		uint4 a, b;
-		__builtin_memcpy(&a, src + lit_start, 16);
-		__builtin_memcpy(&b, src + lit_start + 16, 16);
-		lw[0] = a.x; lw[1] = a.y; lw[2] = a.z; lw[3] = a.w;
-		lw[4] = b.x; lw[5] = b.y; lw[6] = b.z; lw[7] = b.w;
-	}
+	const uint32_t lw[8] = { in.la.x, in.la.y, in.la.z, in.la.w, in.lb.x, in.lb.y, in.lb.z, in.lb.w };
 	uint32_t seg_lo = 0; /* first record of the current run of small records */
 	while (nev) {
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
@@ -1127,28 +1152,23 @@ DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8
 			const uint32_t run_bytes = (seg_hi < 64 ? rdlane(excl, seg_hi & 63) : total) - run_base;
 			const bool in_run = lane >= seg_lo && lane < seg_hi;
 			uint8_t *o = stage + sa + fill + (excl - run_base);
+			/* literal payload first, as whole dwords (unaligned LDS stores): the up to three
+			 * bytes a lane writes past its literal land on its own copy tag and, at most, on the
+			 * first byte of the next record -- always a tag byte -- and both are written below */
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k) {
+				if (!__ballot(in_run && 4 * k < lit_len))
+					break;
+				if (in_run && 4 * k < lit_len)
+					__builtin_memcpy(o + lhdr + 4 * k, &lw[k], 4);
+			}
+			wave_lds_fence();
 			if (in_run) {
 				if (lhdr == 1) {
 					o[0] = (uint8_t)((lit_len - 1) << 2);
 				} else if (lhdr == 2) {
 					o[0] = (uint8_t)(60 << 2);
 					o[1] = (uint8_t)(lit_len - 1);
-				}
-			}
-#pragma unroll
-			for (uint32_t k = 0; k < 8; ++k) {
-				if (!__ballot(in_run && 4 * k < lit_len))
-					break;
-				if (in_run && 4 * k < lit_len) {
-					uint8_t *q = o + lhdr + 4 * k;
-					const uint32_t w = lw[k], rem = lit_len - 4 * k;
-					q[0] = (uint8_t)w;
-					if (rem > 1)
-						q[1] = (uint8_t)(w >> 8);
-					if (rem > 2)
-						q[2] = (uint8_t)(w >> 16);
-					if (rem > 3)
-						q[3] = (uint8_t)(w >> 24);
 				}
 			}
 			if (in_run && clen) {
@@ -1241,17 +1261,54 @@ DEVINL void emit_chunk(const uint2 *R, uint32_t first, uint32_t nev, const uint8
 		seg_lo = e + 1;
 	}
 	drain();
+	return gpos;
 }
 
 constexpr uint32_t kEmitWaves = 4;
 constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records) */
 
-extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_blocks(CompressArgs A)
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blocks(CompressArgs A)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
 	__shared__ uint32_t chunk_tot[kMaxChunks];
 	__shared__ uint32_t chunk_base[kMaxChunks + 1];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (A.emit_wave_per_block) {
+		/* small blocks (pages): one wave per block, chunks in order, no size pass */
+		const uint32_t b = blockIdx.x * kEmitWaves + wv;
+		if (b >= A.emit_blocks)
+			return;
+		const uint32_t blk = A.blk_base + b;
+		const uint32_t len = A.in_len[blk];
+		uint8_t *dst = A.out + A.out_off[blk];
+		uint32_t pos = 0;
+		if (A.mode == CSNAPPY_HIP_STREAM) {
+			pos = varint_len(len);
+			if (lane < pos)
+				dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
+		}
+		const uint32_t cnt = A.rec_cnt[b]; /* fpb == 1 */
+		const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)b * A.rec_cap);
+		const uint8_t *src = A.in + A.in_off[blk];
+		/* records are fetched two chunks ahead, literal bytes one chunk ahead */
+		ChunkIn cur, nxt;
+		nxt.r = fetch_record(R, 0, min(64u, cnt), lane);
+		uint2 r2 = cnt > 64 ? fetch_record(R, 64, min(64u, cnt - 64), lane) : make_uint2(0, 0);
+		if (cnt)
+			fetch_literal(nxt, min(64u, cnt), src, len, lane);
+		for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
+			cur = nxt;
+			nxt.r = r2;
+			if (r0 + 128 < cnt)
+				r2 = fetch_record(R, r0 + 128, min(64u, cnt - r0 - 128), lane);
+			if (r0 + 64 < cnt)
+				fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
+			pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane);
+		}
+		if (lane == 0)
+			A.out_len[blk] = pos;
+		return;
+	}
 	const uint32_t blk = A.blk_base + blockIdx.x;
 	const uint32_t len = A.in_len[blk];
 	const uint32_t nfr = len ? (len + kFragment - 1) / kFragment : 1;
@@ -1270,15 +1327,25 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_blocks
 		const uint8_t *src = A.in + A.in_off[blk] + fi * kFragment;
 		const uint32_t avail = len - fi * kFragment;
 		const uint32_t nchunks = (cnt + 63) >> 6;
-		/* pass 1: encoded bytes of every 64-record chunk */
-		for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
-			const uint32_t r = ch * 64 + lane;
-			const bool live = r < cnt;
-			const RecFields f = decode_record(live ? R[r] : make_uint2(0, 0), live);
-			uint32_t total;
-			(void)wave_excl_scan(f.mine, lane, &total);
-			if (lane == 0)
-				chunk_tot[ch] = total;
+		/* pass 1: encoded bytes of every 64-record chunk (four chunks' records in flight) */
+		for (uint32_t c0 = wv; c0 < nchunks; c0 += 4 * kEmitWaves) {
+			uint2 rr[4];
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				const uint32_t r = (c0 + j * kEmitWaves) * 64 + lane;
+				rr[j] = r < cnt ? R[r] : make_uint2(0, 0);
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				const uint32_t ch = c0 + j * kEmitWaves;
+				if (ch < nchunks) {
+					const RecFields f = decode_record(rr[j], ch * 64 + lane < cnt);
+					uint32_t total;
+					(void)wave_excl_scan(f.mine, lane, &total);
+					if (lane == 0)
+						chunk_tot[ch] = total;
+				}
+			}
 		}
 		__syncthreads();
 		if (wv == 0) {
@@ -1297,9 +1364,28 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_blocks
 				chunk_base[nchunks] = run;
 		}
 		__syncthreads();
-		/* pass 2: every wave encodes its chunks at their final place */
-		for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves)
-			emit_chunk(R, ch * 64, min(64u, cnt - ch * 64), src, avail, dst + chunk_base[ch], stage_all[wv], lane);
+		/* pass 2: every wave encodes its chunks at their final place (records fetched two of
+		 * its chunks ahead, literal bytes one ahead) */
+		{
+			ChunkIn cur, nxt;
+			auto cn = [&](uint32_t ch) { return min(64u, cnt - ch * 64); };
+			uint2 r2 = make_uint2(0, 0);
+			if (wv < nchunks) {
+				nxt.r = fetch_record(R, wv * 64, cn(wv), lane);
+				if (wv + kEmitWaves < nchunks)
+					r2 = fetch_record(R, (wv + kEmitWaves) * 64, cn(wv + kEmitWaves), lane);
+				fetch_literal(nxt, cn(wv), src, avail, lane);
+			}
+			for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
+				cur = nxt;
+				nxt.r = r2;
+				if (ch + 2 * kEmitWaves < nchunks)
+					r2 = fetch_record(R, (ch + 2 * kEmitWaves) * 64, cn(ch + 2 * kEmitWaves), lane);
+				if (ch + kEmitWaves < nchunks)
+					fetch_literal(nxt, cn(ch + kEmitWaves), src, avail, lane);
+				(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + chunk_base[ch], stage_all[wv], lane);
+			}
+		}
 		pos = chunk_base[nchunks];
 		__syncthreads();
 	}
@@ -1982,7 +2068,10 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		}
 		t.stop(0);
 		t.start();
-		hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb), dim3(64 * kEmitWaves), 0, st, A);
+		A.emit_wave_per_block = fpb == 1 && max_in_len <= 8192;
+		A.emit_blocks = nb;
+		hipLaunchKernelGGL(snappy_emit_blocks, dim3(A.emit_wave_per_block ? (nb + kEmitWaves - 1) / kEmitWaves : nb),
+				   dim3(64 * kEmitWaves), 0, st, A);
 		t.stop(1);
 		if (!hip_ok(hipGetLastError(), "launch snappy_emit_blocks"))
 			return CSNAPPY_HIP_E_RUNTIME;
