@@ -114,6 +114,34 @@ def cpu_baseline(kind, seed, block, p, mode, nblocks_avail, target_s, urls=None)
     }
 
 
+def verify_against_reference(torch, api, d_in, b, d_out, chunk, block, p, mode, nv):
+    """Compress the first nv blocks of `chunk` on the GPU and with the CPU checker (all host
+    cores); compare every length and the sha256 of the compacted streams."""
+    import hashlib
+    import oracle
+    lo, cnt = chunk
+    src = d_in[lo * block:(lo + cnt) * block]
+    api.compress_batch(src, b.d_in_off[:cnt], b.d_in_len[:cnt], b.max_in_len, d_out, b.d_out_off[:cnt],
+                       b.d_out_len[:cnt], p, mode, b.d_ws)
+    torch.cuda.synchronize()
+    codec = oracle.best()
+    host = src[:nv * block].cpu().numpy()
+    want, want_len = oracle.batch_compress(codec, host, b.in_off[:nv], b.in_len[:nv], b.out_off[:nv],
+                                           int(b.out_off[nv - 1] + b.slot[nv - 1]), p, mode, threads=os.cpu_count() or 1)
+    got_len = b.d_out_len[:nv].cpu().numpy().astype(np.uint32)
+    got = d_out[:int(b.out_off[nv - 1] + b.slot[nv - 1])].cpu().numpy()
+    slot = int(b.slot[0])
+
+    def compact(buf, lens):
+        m = np.arange(slot, dtype=np.uint32)[None, :] < lens[:, None]
+        return buf[:nv * slot].reshape(nv, slot)[m]
+    ok_len = bool(np.array_equal(got_len, want_len))
+    h_got = hashlib.sha256(compact(got, got_len).tobytes()).hexdigest()
+    h_want = hashlib.sha256(compact(want, want_len).tobytes()).hexdigest()
+    return {"blocks": int(nv), "lengths_equal": ok_len, "sha256_equal": h_got == h_want, "sha256": h_got,
+            "checker": codec.kind}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +156,9 @@ def main():
                          "memory of very large batches; the whole input stays resident)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-gib", type=float, default=1.0,
+                    help="outside the timed region, compare the compressed bytes and lengths of the first "
+                         "this-many GiB of blocks with the CPU reference (0 = round-trip check only)")
     ap.add_argument("--gather", action="store_true",
                     help="also time an RCCL all_gather of the compacted per-rank streams (reported "
                          "separately; never part of `value`)")
@@ -202,6 +233,12 @@ def main():
     # results are checked outside the timed region: every block of every chunk round-trips
     step(check=True)
     comp_bytes = int(comp_total.item())
+    # ... and (rank 0) the first --verify-gib of blocks are bit-exact against the CPU reference:
+    # every compressed length, and the sha256 of the compacted stream
+    bit_exact = None
+    if rank == 0 and args.verify_gib > 0:
+        bit_exact = verify_against_reference(torch, api, d_in, b, d_out, chunks[0], block, p, mode,
+                                             min(chunks[0][1], max(1, int(args.verify_gib * 2 ** 30) // block)))
     for _ in range(max(0, args.warmup - 1)):
         step()
     torch.cuda.synchronize()
@@ -272,6 +309,9 @@ def main():
                    "chunks_per_step": len(chunks),
                    "sharding": f"block ranges, {world} rank(s), no data-path collective"},
         "compressed_ratio": round(comp_bytes / n_bytes, 6),
+        "bit_exact_blocks": (bit_exact["blocks"] if bit_exact and bit_exact["lengths_equal"]
+                             and bit_exact["sha256_equal"] else 0) if bit_exact else None,
+        "bit_exact": bit_exact,
         "compress_gibs": gibs(kernels["snappy_parse_fragments"]["ms_per_step"]
                               + kernels["snappy_emit_blocks"]["ms_per_step"]),
         "decompress_gibs": gibs(kernels["snappy_decompress_blocks"]["ms_per_step"]),

@@ -56,6 +56,11 @@ NEGATIVE = [  # (hex, dst_len)  SURVEY.md Appendix C
     # a few more shapes: copy-4 tag, long literal forms, overrun inside a copy
     ("0c0c61626364fe0400", 12), ("0c0c616263640f04000000", 64), ("05f00461626364 65".replace(" ", ""), 64),
     ("03f4020061", 64), ("0400610500", 64),
+    # a literal tag whose 4-byte length field is ffffffff: length + 1 wraps to 0 (a zero-length literal,
+    # csnappy_decompress.c:368-375) -- alone, between two literals, in front of a copy, as the last tag
+    ("00fcffffffff", 64), ("040c61626364fcffffffff", 64), ("0404 6162 fcffffffff 0463 64".replace(" ", ""), 64),
+    ("080c61626364fcffffffff0d04", 64), ("0400 61 fcffffffff 0562".replace(" ", ""), 64),
+    ("0400 61 fcffffffff 0500".replace(" ", ""), 64), ("04fcffffffff0c61626364", 3),
 ]
 
 
