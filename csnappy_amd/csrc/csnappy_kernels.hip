@@ -101,12 +101,6 @@ DEVINL uint32_t common_prefix16(uint64_t xlo, uint64_t xhi)
 	return zl ? (zl - 1) >> 3 : zh ? 8u + ((zh - 1) >> 3) : 16u;
 }
 
-/* a value that is the same in every lane, as a scalar */
-DEVINL uint32_t uni(uint32_t v)
-{
-	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
 DEVINL uint32_t first_lane(uint64_t m)
 {
 	return (uint32_t)__builtin_ctzll(m);
@@ -568,16 +562,6 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				if (sparse)
 					n_sparse++;
 			}
-			/* the cursor state is the same in every lane: say so (keeps the chain walk on the
-			 * scalar unit) */
-			ip = uni(ip);
-			spec = uni(spec);
-			s = uni(s);
-			qi = uni(qi);
-			next_emit = uni(next_emit);
-			nev = uni(nev);
-			p0 = uni(p0);
-			sparse = uni((uint32_t)sparse) != 0;
 			/* this step's lane state (the next step's is placed before the step ends) */
 			const bool sparse_c = sparse;
 			const uint32_t p0_c = p0, pos_c = pos;
@@ -746,7 +730,6 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 					bool sp = (special >> i) & 1;
 					for (;;) {
 						uint32_t t;
-						i = (int)uni((uint32_t)i);
 						if (sp) {
 							uint32_t L = kLocalMatch;
 							if ((flagmask >> i) & 1) {
