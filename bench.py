@@ -274,13 +274,17 @@ def main():
     api.set_kernel_timing(False)
     kt = api.get_kernel_timing()
 
-    t_max = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = t.item()
+    t_max, t_min, ranks_seen = elapsed, elapsed, 1
     n_bytes = nb * block
-    # a "launch" below is one batch call of the C-ABI (per chunk); ms_per_step sums the chunks
+    kt_ms = [kt[k][0] for k in sorted(kt)]
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        t = torch.tensor([elapsed, -elapsed] + kt_ms, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank, also per kernel
+        t_max, t_min = t[0].item(), -t[1].item()
+        kt = {k: (t[2 + i].item(), kt[k][1]) for i, k in enumerate(sorted(kt))}
+    # a "launch" below is one batch call of the C-ABI (per chunk); ms_per_step sums the chunks;
+    # with several ranks every figure is that of the SLOWEST rank
     kernels = {k: {"avg_ms": round(ms / max(c, 1), 4), "launches": c,
                    "ms_per_step": round(ms / args.steps, 4)} for k, (ms, c) in kt.items()}
 
@@ -326,6 +330,8 @@ def main():
         "unit": "GiB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t_max / args.steps * 1e3, 4),
+        "n_ranks_seen": ranks_seen,
+        "rank_ms_per_step": {"min": round(t_min / args.steps * 1e3, 4), "max": round(t_max / args.steps * 1e3, 4)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic" if kind >= 0 else "urls.10K replicated",
         "config": {"workload": f"{args.gib:g} GiB per GPU of {desc}, {block}-byte blocks, "

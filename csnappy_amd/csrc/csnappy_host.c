@@ -16,16 +16,19 @@
  *   - *dst_len is updated only on CSNAPPY_E_OK                               csnappy_decompress.c:385
  *   - re-entrant: calls are serialised on one mutex-guarded device context
  */
+#ifndef CSNAPPY_HOST_ARITH_ONLY /* (oracle/asan_check.c compiles only the two arithmetic entry points) */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include "../../include/csnappy_hip.h"
+#endif
 
 #include "../../include/csnappy.h"
-#include "../../include/csnappy_hip.h"
 
+#ifndef CSNAPPY_HOST_ARITH_ONLY
 struct buf {
 	void *p;
 	size_t cap;
@@ -83,6 +86,8 @@ struct desc {
 	uint32_t produced, pad;
 };
 
+#endif /* !CSNAPPY_HOST_ARITH_ONLY */
+
 uint32_t csnappy_max_compressed_length(uint32_t source_len)
 {
 	return 32u + source_len + source_len / 6u;
@@ -104,6 +109,7 @@ int csnappy_get_uncompressed_length(const char *start, uint32_t n, uint32_t *res
 	}
 }
 
+#ifndef CSNAPPY_HOST_ARITH_ONLY
 static uint32_t compress_on_device(const char *input, uint32_t n, char *output, int p, int mode)
 {
 	struct desc d;
@@ -224,3 +230,4 @@ int csnappy_decompress_noheader(const char *src, uint32_t src_len, char *dst, ui
 		*dst_len = produced;
 	return rc;
 }
+#endif /* !CSNAPPY_HOST_ARITH_ONLY */

@@ -5,8 +5,13 @@ Blocks (and the 32 KiB fragments inside them) share no state (reference
 csnappy_compress.c:76-84, per-fragment memset :501, offsets relative to the fragment base
 :479,546,550), so rank r of R simply takes the contiguous block range [r*B/R, (r+1)*B/R): the
 compress and decompress kernels need no communication.  RCCL (torch.distributed "nccl") is used
-only to assemble the final stream: an all_gather of the per-rank byte counts followed by an
-all_gather of the compacted per-rank streams, padded to the largest.
+only to assemble the final stream: an all_gather of the per-rank byte counts (8 B
+per rank), then either
+  * gather_to_root   grouped send/recv: every rank sends its compacted stream once, straight into
+                     its place in root's output buffer (no padding, no staging copy; over xGMI the
+                     seven peers use seven different links to root), or
+  * gather_streams   an all_gather padded to the largest stream, when every rank needs the whole
+                     stream.
 """
 import time
 
@@ -55,6 +60,44 @@ def gather_streams(dense, dist, world, group=None):
     return [bufs[r][:sizes[r]] for r in range(world)], sizes
 
 
+def gather_to_root(dense, dist, world, root=0, group=None):
+    """Variable-size gather of the per-rank streams to `root` with grouped point-to-point
+    operations (ncclGroupStart/End under the nccl backend).  The size exchange is the only host
+    synchronisation.  -> (assembled uint8 tensor on root / None elsewhere, sizes list)"""
+    import torch
+    rank = dist.get_rank(group)
+    size = torch.tensor([dense.numel()], dtype=torch.int64, device=dense.device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if rank == root:
+        out = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, device=dense.device)
+        out[int(offs[root]):int(offs[root + 1])] = dense
+        ops = [dist.P2POp(dist.irecv, out[int(offs[r]):int(offs[r + 1])], r, group)
+               for r in range(world) if r != root and sizes[r] > 0]
+    else:
+        out = None
+        ops = [dist.P2POp(dist.isend, dense, root, group)] if dense.numel() > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return (out[:int(offs[-1])] if out is not None else None), sizes
+
+
+def gather_lengths(lens, counts, dist, world, group=None):
+    """all_gather of the per-block compressed lengths when ranks hold different numbers of blocks
+    (block ranges of a batch that does not divide by the world size): padded to the largest count
+    -- B x 4 bytes in total, tiny next to the payload.  -> one int64 tensor in block order."""
+    import torch
+    pad = max(max(counts), 1)
+    mine = torch.zeros(pad, dtype=torch.int64, device=lens.device)
+    mine[:lens.numel()] = lens.to(torch.int64)
+    bufs = [torch.empty(pad, dtype=torch.int64, device=lens.device) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    return torch.cat([bufs[r][:counts[r]] for r in range(world)])
+
+
 def time_gather_compacted(d_out, b, dist, world, reps=3):
     """Time compaction + the RCCL gather of the final stream (reported next to, never inside,
     the codec throughput)."""
@@ -64,10 +107,11 @@ def time_gather_compacted(d_out, b, dist, world, reps=3):
     t0 = time.perf_counter()
     for _ in range(reps):
         dense, _ = compact(d_out, b.d_out_off, b.d_out_len)
-        parts, sizes = gather_streams(dense, dist, world)
+        _, sizes = gather_to_root(dense, dist, world)
     torch.cuda.synchronize()
     dist.barrier()
     dt = (time.perf_counter() - t0) / reps
     total = int(np.sum(sizes))
     return {"ms": round(dt * 1e3, 3), "gathered_bytes": total,
-            "GBps": round(total / dt / 1e9, 3), "what": "compact + all_gather of per-rank streams"}
+            "GBps": round(total / dt / 1e9, 3),
+            "what": "compact + size exchange + grouped send/recv of the per-rank streams to rank 0"}

@@ -290,3 +290,46 @@ def test_batch_drivers_match_single_calls(port, urls):
     back, status, _ = oracle.batch_decompress(port, out, b.out_off, out_len, b.in_off, b.in_len,
                                               b.in_bytes, oracle.STREAM, threads=4)
     assert (status == 0).all() and bytes(back) == urls
+
+
+def test_sanitizer_build_of_the_cpu_side(port, urls, tmp_path):
+    """the reference's `make check_leaks` runs its tester under valgrind
+    (reference Makefile:31-35); valgrind is not in the image, so the CPU restatement and the
+    product's two host-arithmetic entry points (csnappy_host.c) are compiled with
+    -fsanitize=address,undefined (oracle/Makefile: asan_check) and run over the KATs, the negative
+    vectors and a fuzz set, every buffer malloc'ed at its exact size."""
+    import struct
+    import subprocess
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), os.path.join(root, "oracle", "asan_check")])
+    recs = []
+
+    def rec(kind, pc, data, want_rc, want):
+        recs.append(struct.pack("<IiIiI", kind, pc, len(data), want_rc, len(want)) + bytes(data) + bytes(want))
+    from golden.make_golden import kat_inputs
+    for name, data in kat_inputs().items():
+        for p in (15, 16, 9):
+            rec(1, p, data, 0, port.compress(data, p))
+        rec(2, 13, data[:32768], 0, port.compress_fragment(data[:32768], 13))
+    for x, p in _fuzz_inputs(4242, 150, 70000):
+        x = bytes(x)
+        rec(1, p, x, 0, port.compress(x, p))
+        rec(2, p, x[:32768], 0, port.compress_fragment(x[:32768], p))
+    rec(1, 15, urls[:200000], 0, port.compress(urls[:200000], 15))
+    for e in GOLD["negative"]:
+        raw = bytes.fromhex(e["hex"])
+        # (kind 5 carries the expected value in the p_or_cap field)
+        val = e["get_len"][1] if e["get_len"][0] > 0 else 0
+        rec(5, val - (1 << 32) if val >= (1 << 31) else val, raw, e["get_len"][0], b"")
+        rec(3, e["dst_len"], raw, e["decompress"], b"")
+        if "noheader" in e:
+            body = raw[e["get_len"][0]:]
+            rec(4, e["dst_len"], body, e["noheader"][0], bytes.fromhex(e["noheader"][2] or "") if e["noheader"][0] == 0 else b"")
+    bad = open(os.path.join(HERE, "golden", "baddata3.snappy"), "rb").read()
+    rec(3, GOLD["baddata3"]["get_len"][1], bad, GOLD["baddata3"]["decompress"], b"")
+    path = tmp_path / "vectors.bin"
+    path.write_bytes(b"".join(recs))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(root, "oracle", "asan_check"), str(path)], capture_output=True, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert b"asan_check ok" in r.stdout and str(len(recs)).encode() in r.stdout

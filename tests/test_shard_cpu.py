@@ -51,30 +51,38 @@ def _worker(rank, world, port, ret):
     try:
         g = GOLD["workloads"]["G_text_64k_p16"]
         first, count = shard.block_range(g["nblocks"], rank, world)
+        counts = [shard.block_range(g["nblocks"], r, world)[1] for r in range(world)]
         # any block range can be generated independently on any rank
         host = api.generate_host(g["kind"], g["seed"], first, count, g["block"])
         outs = oracle.Port().compress_blocks(host, g["block"], g["p"], g["mode"])
         dense = torch.from_numpy(np.frombuffer(b"".join(outs), dtype=np.uint8).copy())
-        parts, sizes = shard.gather_streams(dense, dist, world)
+        parts, sizes = shard.gather_streams(dense, dist, world)            # everyone gets everything
+        rooted, sizes2 = shard.gather_to_root(dense, dist, world, root=0)  # grouped send/recv to rank 0
         lens = torch.tensor([len(o) for o in outs], dtype=torch.int64)
-        all_lens = [torch.zeros(shard.block_range(g["nblocks"], r, world)[1], dtype=torch.int64)
-                    for r in range(world)]
-        dist.all_gather(all_lens, lens) if len({len(x) for x in all_lens}) == 1 else None
+        all_lens = shard.gather_lengths(lens, counts, dist, world)         # uneven ranges too
+        assert (rooted is None) == (rank != 0)
         if rank == 0:
             stream = b"".join(bytes(p.numpy()) for p in parts)
             ret["sha"] = hashlib.sha256(stream).hexdigest()
+            ret["sha_rooted"] = hashlib.sha256(bytes(rooted.numpy())).hexdigest()
             ret["sizes"] = sizes
-            ret["lens"] = torch.cat(all_lens).tolist()
+            ret["sizes_rooted"] = sizes2
+            ret["lens"] = all_lens.tolist()
+            ret["counts"] = counts
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_two_rank_gather_reassembles_the_single_process_stream(world):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_reassembles_the_single_process_stream(world):
+    """64 blocks over 2 ranks (even) and over 3 ranks (21 / 21 / 22 blocks): both gathers give the
+    unsharded stream, and the per-block lengths arrive in block order."""
     g = GOLD["workloads"]["G_text_64k_p16"]
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret["sha"] == g["sha256"]          # rank-order concatenation == unsharded stream
-    assert sum(ret["sizes"]) == sum(g["lens"])
+    assert ret["sha_rooted"] == g["sha256"]
+    assert sum(ret["sizes"]) == sum(g["lens"]) and ret["sizes_rooted"] == ret["sizes"]
     assert ret["lens"] == g["lens"]
+    assert sum(ret["counts"]) == g["nblocks"] and (world != 3 or len(set(ret["counts"])) == 2)
