@@ -14,9 +14,14 @@
  *   - caller owns all buffers; working_memory is accepted and ignored        csnappy.h:46-72
  *   - compress cannot fail and does not bound-check `output`                 cl_tester.c:120-165
  *   - *dst_len is updated only on CSNAPPY_E_OK                               csnappy_decompress.c:385
- *   - re-entrant: calls are serialised on one mutex-guarded device context
+ *   - re-entrant: calls are serialised on one mutex-guarded device context (plumbing: one
+ *     synchronous H2D -> launch -> D2H per call; the device buffers grow to the largest call and
+ *     are kept for the life of the process)
+ * Differences a caller can observe (also in INTEGRATION.md):
+ *   - on -3 / -5 the reference has written the bytes decoded so far into dst; here dst is untouched
+ *   - a failing HIP runtime (no device, hipMalloc) returns CSNAPPY_E_HIP_UNAVAILABLE (-100)
  */
-#ifndef CSNAPPY_HOST_ARITH_ONLY /* (oracle/asan_check.c compiles only the two arithmetic entry points) */
+#ifndef CSNAPPY_HOST_ARITH_ONLY /* (the sanitizer driver of the test tree compiles only the two arithmetic entry points) */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
@@ -211,20 +216,34 @@ out:
 	return status;
 }
 
+/* Most bytes a Snappy body of n bytes can expand to: a 3-byte copy tag yields up to 64 bytes. */
+static uint32_t expansion_bound(uint32_t n)
+{
+	uint64_t b = (uint64_t)n * 22 + 64;
+	return b > 0xffffffffull ? 0xffffffffu : (uint32_t)b;
+}
+
 int csnappy_decompress(const char *src, uint32_t src_len, char *dst, uint32_t dst_len)
 {
-	uint32_t produced = 0, olen = 0, alloc = dst_len;
-	/* The kernel never writes past min(dst_len, header length): size the device buffer by the
-	 * header when it parses.  The kernel itself re-does every check of the reference. */
-	if (csnappy_get_uncompressed_length(src, src_len, &olen) > 0 && olen < alloc)
-		alloc = olen;
+	uint32_t produced = 0, olen = 0, alloc;
+	/* header errors are decided on the host, as in the reference, before anything is allocated:
+	 * -1 for an unparsable length, -2 when dst is too small (csnappy_decompress.c:399-409) */
+	if (csnappy_get_uncompressed_length(src, src_len, &olen) < 0)
+		return CSNAPPY_E_HEADER_BAD;
+	if (olen > dst_len)
+		return CSNAPPY_E_OUTPUT_INSUF;
+	/* the kernel never writes past the header length, nor can the body expand past its bound */
+	alloc = olen < expansion_bound(src_len) ? olen : expansion_bound(src_len);
 	return decompress_on_device(src, src_len, dst, dst_len, alloc, &produced, CSNAPPY_HIP_STREAM);
 }
 
 int csnappy_decompress_noheader(const char *src, uint32_t src_len, char *dst, uint32_t *dst_len)
 {
 	uint32_t produced = 0;
-	int rc = decompress_on_device(src, src_len, dst, *dst_len, *dst_len, &produced,
+	/* *dst_len is "space available" and may be huge: the device buffer is sized by what src_len
+	 * bytes can expand to, not by it */
+	uint32_t alloc = *dst_len < expansion_bound(src_len) ? *dst_len : expansion_bound(src_len);
+	int rc = decompress_on_device(src, src_len, dst, *dst_len, alloc, &produced,
 				      CSNAPPY_HIP_FRAGMENT);
 	if (rc == CSNAPPY_E_OK)
 		*dst_len = produced;

@@ -36,6 +36,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/csnappy.h"
 #include "../../include/csnappy_hip.h"
 #include "workload_gen.h"
@@ -68,6 +70,7 @@ struct CompressArgs {
 	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
 	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
 	uint32_t only_unparsed; /* TAB_GLOBAL: skip fragments that already have records */
+	uint32_t max_in_len; /* the caller's bound on in_len[]: a longer block is refused (out_len = 0xffffffff) */
 	uint32_t emit_wave_per_block, emit_blocks; /* emit: one wave per block (fpb == 1, small blocks) */
 	uint32_t sample_min;    /* TAB_LDS_DENSE: full fragments with fewer distinct sampled hashes go to TAB_GLOBAL */
 	int p;
@@ -253,8 +256,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 	const uint32_t blk = A.blk_base + c / A.fpb, fi = c % A.fpb;
 	const uint32_t len = A.in_len[blk];
 	const uint32_t foff = fi * kFragment;
-	if (fi > 0 && foff >= len)
-		return;
+	if ((fi > 0 && foff >= len) || len > A.max_in_len)
+		return; /* (a block longer than the caller promised has no room in the workspace) */
 	if (GTAB && A.only_unparsed && A.rec_cnt[c] != kNoRecords)
 		return; /* second launch: only what the dense parser handed over */
 	const uint32_t n = min(len - foff, kFragment);
@@ -1263,6 +1266,11 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 			return;
 		const uint32_t blk = A.blk_base + b;
 		const uint32_t len = A.in_len[blk];
+		if (len > A.max_in_len) {
+			if (lane == 0)
+				A.out_len[blk] = 0xffffffffu;
+			return;
+		}
 		uint8_t *dst = A.out + A.out_off[blk];
 		uint32_t pos = 0;
 		if (A.mode == CSNAPPY_HIP_STREAM) {
@@ -1294,6 +1302,12 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 	}
 	const uint32_t blk = A.blk_base + blockIdx.x;
 	const uint32_t len = A.in_len[blk];
+	if (len > A.max_in_len) {
+		/* the precondition in_len[b] <= max_in_len is violated: nothing was parsed for this block */
+		if (tid == 0)
+			A.out_len[blk] = 0xffffffffu;
+		return;
+	}
 	const uint32_t nfr = len ? (len + kFragment - 1) / kFragment : 1;
 	uint8_t *dst = A.out + A.out_off[blk];
 	uint32_t pos = 0;
@@ -1691,12 +1705,21 @@ unsigned long long *g_prof_buf = nullptr;
 bool g_timing = false;
 Pending g_pending[4096];
 int g_npending = 0;
+std::mutex g_timing_mu; /* guards g_pending / g_npending (batch calls may come from several threads) */
 
 struct Timer {
 	hipStream_t st;
 	hipEvent_t a = nullptr, b = nullptr;
 	bool on;
-	explicit Timer(hipStream_t s) : st(s), on(g_timing && g_npending < 4096) {}
+	explicit Timer(hipStream_t s) : st(s), on(g_timing) {}
+	~Timer()
+	{
+		/* an error path left between start() and stop(): do not leak the events */
+		if (a)
+			(void)hipEventDestroy(a);
+		if (b)
+			(void)hipEventDestroy(b);
+	}
 	void start()
 	{
 		if (!on)
@@ -1707,11 +1730,14 @@ struct Timer {
 	}
 	void stop(int slot)
 	{
-		if (!on)
+		if (!on || !a)
 			return;
 		(void)hipEventRecord(b, st);
-		g_pending[g_npending++] = Pending{ slot, a, b };
-		on = g_timing && g_npending < 4096;
+		std::lock_guard<std::mutex> lock(g_timing_mu);
+		if (g_npending < 4096) {
+			g_pending[g_npending++] = Pending{ slot, a, b };
+			a = b = nullptr;
+		}
 	}
 };
 
@@ -1944,6 +1970,7 @@ void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4])
 		ms[i] = 0;
 		launches[i] = 0;
 	}
+	std::lock_guard<std::mutex> lock(g_timing_mu);
 	for (int i = 0; i < g_npending; ++i) {
 		float t = 0;
 		(void)hipEventSynchronize(g_pending[i].b);
@@ -2006,6 +2033,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.rec_cap = W.rec_cap;
 	A.tab_stride = W.tab_stride;
 	A.dense_cap = P.dense_cap;
+	A.max_in_len = max_in_len;
 	A.sample_min = P.sample_min;
 	A.p = p;
 	A.mode = mode;

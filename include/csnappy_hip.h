@@ -43,14 +43,18 @@ const char *csnappy_hip_last_error(void);
 
 /*
  * Device scratch needed by csnappy_hip_compress_batch for `nblocks` blocks whose lengths are
- * all <= max_in_len.  (Per-fragment staging slots for the 2nd.. fragments of each block and the
- * per-fragment length table; 256-byte aligned base required.)
+ * all <= max_in_len: per 32 KiB fragment the parser's 8-byte (literal, copy) records (one per four
+ * input bytes at most), the 2-byte bucket ids of its positions (or its global-memory hash table)
+ * and a record count.  A batch is processed in chunks of 32768 fragments, so the size stops
+ * growing there (about 6 GiB for 64 KiB blocks).  256-byte aligned base required.
  */
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len);
 
 /*
  * Compress nblocks independent blocks.
- *   d_in, d_in_off[b], d_in_len[b]   input bytes of block b            (in_len[b] <= max_in_len)
+ *   d_in, d_in_off[b], d_in_len[b]   input bytes of block b            (in_len[b] <= max_in_len: the
+ *                                    workspace is sized by max_in_len; a longer block is not
+ *                                    compressed and gets d_out_len[b] = 0xffffffff)
  *   d_out, d_out_off[b]              start of block b's output slot, which must hold
  *                                    csnappy_max_compressed_length(in_len[b]) bytes (unchecked,
  *                                    as in the reference)
@@ -87,11 +91,17 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
 			      const uint64_t *d_dense_off, uint32_t nblocks, void *d_dense, void *stream);
 
 /*
+ * Thread safety: the batch calls keep no state between calls and may be issued from several
+ * threads (each with its own buffers, workspace and, preferably, stream); the timing list below is
+ * mutex-guarded.  csnappy_hip_last_error() is per thread.  The CSNAPPY_HIP_* environment knobs
+ * (experiments; see csnappy_kernels.hip) are read and range-checked on every compress batch call;
+ * a bad value makes the call return CSNAPPY_HIP_E_ARG.
+ *
  * Per-kernel timing for bench.py: while enabled, the batch calls record a hipEvent pair on
  * `stream` around each kernel (nothing synchronises in the launch path).
  * csnappy_hip_get_kernel_timing() waits for the recorded events, returns the summed duration
  * (milliseconds) and the number of launches per kernel since the previous read, and resets.
- * slots: [0] snappy_parse_fragments  [1] snappy_emit_blocks  [2] snappy_decompress_blocks
+ * slots: [0] snappy_parse_fragments (all its launches)  [1] snappy_emit_blocks  [2] snappy_decompress_blocks
  */
 void csnappy_hip_set_kernel_timing(int enable);
 void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4]);

@@ -68,7 +68,7 @@ static double now(void)
 	return t.tv_sec + t.tv_nsec * 1e-9;
 }
 
-static int compress_file(const char *in_name, const char *out_name)
+static int compress_file(const char *in_name, const char *out_name, int per_page)
 {
 	size_t n, slot = csnappy_max_compressed_length(PAGE), ws;
 	char *in = read_all(in_name, &n);
@@ -96,14 +96,33 @@ static int compress_file(const char *in_name, const char *out_name)
 	    hipMemcpy(d_off, off, 2 * (size_t)nr * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(d_len, len, (size_t)nr * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
 		die("hipMemcpy H2D");
-	t0 = now();
-	if (nr && csnappy_hip_compress_batch(d_in, (uint64_t *)d_off, (uint32_t *)d_len, nr, PAGE, d_out,
-					     (uint64_t *)d_off + nr, (uint32_t *)d_len + nr, ORDER,
-					     CSNAPPY_HIP_FRAGMENT, d_ws, ws, NULL))
-		die("csnappy_hip_compress_batch");
-	if (hipDeviceSynchronize() != hipSuccess)
-		die("compress kernels");
-	t1 = now();
+	if (per_page) {
+		/* -1: the reference's loop (block_compressor.c:307-337): one call per page, its time
+		 * taken around that call alone and summed -- here one 1-block launch + wait per page,
+		 * pages resident on the device.  This is the latency of a call, not the throughput. */
+		double sum = 0;
+		for (i = 0; i < nr; i++) {
+			t0 = now();
+			if (csnappy_hip_compress_batch(d_in, (uint64_t *)d_off + i, (uint32_t *)d_len + i, 1, PAGE, d_out,
+						       (uint64_t *)d_off + nr + i, (uint32_t *)d_len + nr + i, ORDER,
+						       CSNAPPY_HIP_FRAGMENT, d_ws, ws, NULL))
+				die("csnappy_hip_compress_batch");
+			if (hipDeviceSynchronize() != hipSuccess)
+				die("compress kernels");
+			sum += now() - t0;
+		}
+		t0 = 0;
+		t1 = sum;
+	} else {
+		t0 = now();
+		if (nr && csnappy_hip_compress_batch(d_in, (uint64_t *)d_off, (uint32_t *)d_len, nr, PAGE, d_out,
+						     (uint64_t *)d_off + nr, (uint32_t *)d_len + nr, ORDER,
+						     CSNAPPY_HIP_FRAGMENT, d_ws, ws, NULL))
+			die("csnappy_hip_compress_batch");
+		if (hipDeviceSynchronize() != hipSuccess)
+			die("compress kernels");
+		t1 = now();
+	}
 	if (hipMemcpy(len + nr, (uint32_t *)d_len + nr, (size_t)nr * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
 	    hipMemcpy(out, d_out, (size_t)nr * slot, hipMemcpyDeviceToHost) != hipSuccess)
 		die("hipMemcpy D2H");
@@ -135,6 +154,9 @@ static int compress_file(const char *in_name, const char *out_name)
 	}
 	fclose(f);
 	printf("> 100%%\t:%u\n> 50%%\t:%u\n<= 50%%\t:%u\n%.9f seconds\n", counts[2], counts[1], counts[0], t1 - t0);
+	if (nr)
+		printf("%.0f ns per page (%s)\n", (t1 - t0) * 1e9 / nr,
+		       per_page ? "one launch + wait per page, as the reference times it" : "one batch launch / #pages");
 	return 0;
 }
 
@@ -152,13 +174,15 @@ static int decompress_file(const char *in_name, const char *out_name)
 		die("short container");
 	memcpy(&nr, in, 4);
 	printf("nr_pages: %u\n", nr);
-	if ((size_t)(nr + 1) * 4 > n)
+	if ((size_t)nr > (n - 4) / 4) /* (the header is untrusted: no 32-bit arithmetic on it) */
 		die("short container");
 	len = malloc(4 * (size_t)nr * sizeof(uint32_t) + 16); /* in_len | out_cap | status | produced */
 	off = malloc(2 * (size_t)nr * sizeof(uint64_t) + 16);
 	out = malloc((size_t)nr * PAGE + 16);
+	if (!len || !off || !out)
+		die("out of memory");
 	status = (int32_t *)(len + 2 * (size_t)nr);
-	pos = (size_t)(nr + 1) * 4;
+	pos = ((size_t)nr + 1) * 4;
 	for (i = 0; i < nr; i++) {
 		memcpy(&len[i], in + 4 + 4 * (size_t)i, 4);
 		off[i] = pos;
@@ -212,10 +236,12 @@ static int decompress_file(const char *in_name, const char *out_name)
 
 int main(int argc, char *const argv[])
 {
-	int c, decompress = 0, have_method = 0;
-	while ((c = getopt(argc, argv, "dc:")) != -1) {
+	int c, decompress = 0, have_method = 0, per_page = 0;
+	while ((c = getopt(argc, argv, "d1c:")) != -1) {
 		if (c == 'd')
 			decompress = 1;
+		else if (c == '1')
+			per_page = 1;
 		else if (c == 'c' && !strcmp(optarg, "snappy"))
 			have_method = 1;
 		else
@@ -226,8 +252,8 @@ int main(int argc, char *const argv[])
 	if (csnappy_hip_device_count() <= 0)
 		die("no usable HIP device");
 	return decompress ? decompress_file(argv[optind], argv[optind + 1])
-			  : compress_file(argv[optind], argv[optind + 1]);
+			  : compress_file(argv[optind], argv[optind + 1], per_page);
 usage:
-	fprintf(stderr, "usage: block_compressor -c snappy [-d] infile outfile\n");
+	fprintf(stderr, "usage: block_compressor -c snappy [-d] [-1] infile outfile\n");
 	return 1;
 }
