@@ -69,7 +69,7 @@ struct CompressArgs {
 	uint32_t dense_cap; /* entries of the dense LDS table */
 	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
 	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
-	uint32_t only_unparsed; /* TAB_GLOBAL: skip fragments that already have records */
+	uint32_t only_unparsed; /* skip fragments that already have records (second and later launches) */
 	uint32_t max_in_len; /* the caller's bound on in_len[]: a longer block is refused (out_len = 0xffffffff) */
 	uint32_t emit_wave_per_block, emit_blocks; /* emit: one wave per block (fpb == 1, small blocks) */
 	uint32_t sample_min;    /* TAB_LDS_DENSE: full fragments with fewer distinct sampled hashes go to TAB_GLOBAL */
@@ -102,6 +102,13 @@ DEVINL uint32_t common_prefix16(uint64_t xlo, uint64_t xhi)
 {
 	const uint32_t zl = (uint32_t)__ffsll((unsigned long long)xlo), zh = (uint32_t)__ffsll((unsigned long long)xhi);
 	return zl ? (zl - 1) >> 3 : zh ? 8u + ((zh - 1) >> 3) : 16u;
+}
+
+/* lanes whose predicate holds (the builtin takes the i1 itself: HIP's __ballot(int) makes the compiler
+ * materialise 0/1 in a VGPR and compare it again) */
+DEVINL uint64_t ballot64(bool p)
+{
+	return __builtin_amdgcn_ballot_w64(p);
 }
 
 DEVINL uint32_t first_lane(uint64_t m)
@@ -226,7 +233,8 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
 constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging */
 constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
-constexpr uint32_t kNoRecords = 0xffffffffu; /* rec_cnt: "not parsed yet, needs the global-table parser" */
+constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
+constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
 constexpr bool kTouchAhead = true;          /* parser: touch the input / id lines of the step after next */
 constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
 
@@ -258,8 +266,12 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 	const uint32_t foff = fi * kFragment;
 	if ((fi > 0 && foff >= len) || len > A.max_in_len)
 		return; /* (a block longer than the caller promised has no room in the workspace) */
-	if (GTAB && A.only_unparsed && A.rec_cnt[c] != kNoRecords)
-		return; /* second launch: only what the dense parser handed over */
+	if (A.only_unparsed) {
+		/* a later launch of the batch call: only what the earlier ones handed over */
+		const uint32_t state = A.rec_cnt[c];
+		if (state != kNoRecords && !(GTAB && state == kWantGlobal))
+			return;
+	}
 	const uint32_t n = min(len - foff, kFragment);
 	const int ws = fragment_power(n, A.p, A.mode);
 	const uint32_t shift = 33 - ws;
@@ -316,7 +328,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				wave_lds_fence();
 				if (distinct < A.sample_min) {
 					if (lane == 0)
-						A.rec_cnt[c] = kNoRecords;
+						A.rec_cnt[c] = kWantGlobal;
 					return;
 				}
 			}
@@ -486,7 +498,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				m8 = z ? min((z - 1) >> 3, r) : r;
 				term = m8 < 8 || o + 8 >= lim;
 			}
-			const uint64_t tmask = __ballot(term);
+			const uint64_t tmask = ballot64(term);
 			if (tmask) {
 				const uint32_t t = first_lane(tmask);
 				return done + 8 * t + rdlane(m8, t);
@@ -604,8 +616,8 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			if (A.s_shift)
 				first_same = max(first_same, S2[key2] & 63u);
 			const bool flagged = tabbed && first_same < lane;
-			uint64_t cmask = __ballot(flagged); /* flagged lanes */
-			const uint64_t imask = ~__ballot(valid_c);
+			uint64_t cmask = ballot64(flagged); /* flagged lanes */
+			const uint64_t imask = ~ballot64(valid_c);
 			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
 			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
 			int ulim = sparse_c ? min(c1, v) : v;
@@ -631,7 +643,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			uint32_t mlen = common_prefix16(xlo, xhi);
 			if (!maybe || (GTAB && flagged))
 				mlen = 0; /* (nothing was gathered for a flagged lane of the global placement) */
-			const uint64_t matchmask = __ballot((int)lane < ulim && mlen >= 4);
+			const uint64_t matchmask = ballot64((int)lane < ulim && mlen >= 4);
 			epoch--;
 			if (PROF) {
 				t1 = __builtin_amdgcn_s_memtime();
@@ -686,7 +698,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				if (PROF)
 					n_flagged += __builtin_popcountll(flagmask);
 				const uint64_t stopmask = matchmask | flagmask;
-				const uint64_t widemask = __ballot(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
+				const uint64_t widemask = ballot64(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
 				const uint64_t special = widemask | flagmask; /* stops that are not plain matches */
 				uint32_t nx; /* ... | 128 when that next stop is a special lane */
 				{
@@ -747,9 +759,9 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 								const uint64_t below = taken & lt_mask;
 								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
 								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-								const uint64_t ins = ((1ull << i) - 1) & ~__ballot(below != 0 && lane + 1 < cprev);
+								const uint64_t ins = ((1ull << i) - 1) & ~ballot64(below != 0 && lane + 1 < cprev);
 								const uint32_t slot_i = rdlane(slot, i);
-								const uint64_t same = __ballot(tabbed & (slot == slot_i)) & ins;
+								const uint64_t same = ballot64(tabbed & (slot == slot_i)) & ins;
 								if (same) {
 									if (PROF)
 										n_fwd++;
@@ -931,13 +943,13 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			{
 				/* of several committed lanes with one slot only the last may write (flagged lanes
 				 * that the chain inserted; sparse steps never commit one) */
-				const uint64_t cm = __ballot(commit);
+				const uint64_t cm = ballot64(commit);
 				uint64_t fl = cmask & cm;
 				uint64_t dead = 0;
 				while (fl) {
 					const uint32_t x = first_lane(fl);
 					fl &= fl - 1;
-					dead |= __ballot(slot == rdlane(slot, x)) & cm & ((1ull << x) - 1);
+					dead |= ballot64(slot == rdlane(slot, x)) & cm & ((1ull << x) - 1);
 				}
 				if ((dead >> lane) & 1)
 					commit = false;
@@ -1125,7 +1137,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	const uint32_t lhdr = f.lhdr, mine = f.mine;
 	const CopyPlan cp = f.cp;
 	const bool small = record_is_small(f, live, avail);
-	uint64_t bigmask = __ballot(live && !small);
+	uint64_t bigmask = ballot64(live && !small);
 	uint32_t total;
 	const uint32_t excl = wave_excl_scan(mine, lane, &total);
 	const uint32_t lw[8] = { in.la.x, in.la.y, in.la.z, in.la.w, in.lb.x, in.lb.y, in.lb.z, in.lb.w };
@@ -1143,7 +1155,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 			 * first byte of the next record -- always a tag byte -- and both are written below */
 #pragma unroll
 			for (uint32_t k = 0; k < 8; ++k) {
-				if (!__ballot(in_run && 4 * k < lit_len))
+				if (!ballot64(in_run && 4 * k < lit_len))
 					break;
 				if (in_run && 4 * k < lit_len)
 					__builtin_memcpy(o + lhdr + 4 * k, &lw[k], 4);
@@ -1474,6 +1486,17 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	const uint32_t n = A.in_len[blk];
 	uint8_t *dst = A.out + A.out_off[blk];
 	const uint32_t cap = A.out_cap[blk];
+	/* the tag table, computed once per wave (4 entries per lane) */
+	__shared__ uint16_t ctab[256];
+	for (uint32_t b = lane; b < 256; b += 64) {
+		const uint32_t kd = b & 3, up = b >> 2;
+		const uint32_t lx = max(up, 59u) - 59u;          /* literal: extra length bytes 0..4, :351-353 */
+		const uint32_t cx = kd + ((kd >> 1) & kd);        /* copy: offset bytes 1, 2, 4 */
+		const uint32_t len = kd == 1 ? 4 + (up & 7) : up + 1;
+		ctab[b] = (uint16_t)((kd == 0 && lx ? 0 : len) | ((kd == 0 ? lx : cx) << 7) |
+				     ((kd == 1 ? b >> 5 : 0u) << 10) | ((kd == 0 ? 1u : 0u) << 13));
+	}
+	wave_lds_fence();
 
 	uint32_t ip = 0;
 	uint32_t limit = cap;
@@ -1526,23 +1549,21 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
 			asm volatile("" : "+v"(b0), "+v"(tr));
 		}
-		/* (flat arithmetic and selects, no branches: the bytes that are not tags decode to every
-		 * kind, so every branch would be taken by some lane anyway) */
-		const uint32_t kind = b0 & 3;
-		const uint32_t up = b0 >> 2;
-		const bool is_lit = kind == 0, is_c1 = kind == 1;
-		const uint32_t lx = max(up, 59u) - 59u;               /* literal: extra length bytes 0..4, :351-353 */
-		const uint32_t cx = kind + ((kind >> 1) & kind);       /* copy: offset bytes 1, 2, 4 */
-		const uint32_t extra = is_lit ? lx : cx;
+		/* one LDS load of the reference's char_table entry (csnappy_decompress.c:152-185, here:
+		 * bits 0-6 length, 7-9 extra bytes, 10-12 offset bits 8..10 of a 1-byte-offset copy,
+		 * 13 literal), then what the reference does with it (:348-365) as selects */
+		const uint32_t e = ctab[b0];
+		const uint32_t extra = (e >> 7) & 7u;
+		const bool is_lit = (e >> 13) & 1u;
+		const uint32_t kind = is_lit ? 0u : 1u; /* only "literal or copy" matters below */
 		const uint32_t xmask = 0xffffffffu >> ((32u - 8u * extra) & 31u); /* extra 0 -> all ones (unused) */
 		const uint32_t trm = tr & xmask;
-		const uint32_t l_short = is_c1 ? 4 + (up & 7) : up + 1;
-		const uint32_t l = (is_lit && lx != 0) ? trm + 1 : l_short;
-		const uint32_t off = is_lit ? 0u : trm | (is_c1 ? (b0 >> 5) << 8 : 0u);
+		const uint32_t l = (is_lit && extra != 0) ? trm + 1 : (e & 127u);
+		const uint32_t off = is_lit ? 0u : trm | (((e >> 10) & 7u) << 8);
 		const uint32_t hsz = 1 + extra;
 		/* bytes this element takes in the input (a literal length that would wrap 32 bits is
 		 * negative as int32 and fails below whatever the walk does after it) */
-		const uint32_t esz = kind == 0 ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
+		const uint32_t esz = is_lit ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
 
 		/* ---- walk the real tag chain on the scalar unit ---- */
 		uint64_t tmask = 0;
@@ -1578,7 +1599,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN
 				      : lit_neg ? CSNAPPY_E_DATA_MALFORMED : 0;
 		const int32_t err = istag ? err_tag : 0;
-		const uint64_t emask = __ballot(err != 0);
+		const uint64_t emask = ballot64(err != 0);
 		const uint32_t fe = emask ? first_lane(emask) : 64;
 		const uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask; /* elements to execute */
 		const bool exec_me = (run >> lane) & 1;
@@ -1592,7 +1613,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const bool cpy = exec_me && kind != 0;
 		const bool indep = cpy && off >= excl + l;
 		copy_exact(edst, lit ? lsrc : edst - off, l, (lit && l <= 64) || indep, next8);
-		for (uint64_t big = __ballot(lit && l > 64); big; big &= big - 1) {
+		for (uint64_t big = ballot64(lit && l > 64); big; big &= big - 1) {
 			const uint32_t t = first_lane(big);
 			const uint32_t L = rdlane(l, t);
 			const uint8_t *ps = src + (ip + t + rdlane(hsz, t));
@@ -1616,7 +1637,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				pd[body + lane] = ps[body + lane];
 		}
 		/* ---- pass 3: the other copies, in order (SAW__AppendFromSelf, :295-317) ---- */
-		for (uint64_t dep = __ballot(cpy && !indep); dep; dep &= dep - 1) {
+		for (uint64_t dep = ballot64(cpy && !indep); dep; dep &= dep - 1) {
 			const uint32_t t = first_lane(dep);
 			const uint32_t L = rdlane(l, t), OFF = rdlane(off, t);
 			uint8_t *pd = dst + (op + rdlane(excl, t));
@@ -1743,7 +1764,8 @@ struct Timer {
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
-constexpr uint32_t kDenseCapDefault = 5632; /* entries of the dense LDS table (11 KiB): URL-like text has 4.5-5.5 k buckets per fragment */
+constexpr uint32_t kDenseCapDefault = 5120; /* entries of the dense LDS table (10 KiB; 14 fragments per CU) */
+constexpr uint32_t kDenseCap2 = 7168;       /* ... of the second dense launch (14 KiB; 10 per CU) */
 constexpr uint32_t kSampleMinDefault = 700; /* of 2048 sampled positions (text: ~1400, runs: ~300) */
 constexpr uint32_t kHashLdsMaxBytes = 8192; /* tables up to this size are indexed by the hash in LDS */
 
@@ -1817,6 +1839,7 @@ struct ParsePlan {
 	int tab;            /* TAB_* of the first launch */
 	uint32_t lds0, lds_bytes, dense_cap, s_entries, s_shift;
 	uint32_t sample_min;
+	uint32_t cap2, lds0_2, lds_bytes_2, s_entries_2, s_shift_2; /* second dense launch (0 = none) */
 	bool fallback;      /* a TAB_GLOBAL launch follows for fragments the dense table cannot hold */
 	uint32_t g_lds0, g_lds_bytes, g_s_entries, g_s_shift;
 };
@@ -1841,9 +1864,11 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	ParsePlan P;
 	memset(&P, 0, sizeof(P));
 	const uint32_t slots = 1u << (p - 1);
-	/* two 256-entry filters: a false alarm only costs a visit of the flagged lane when the chain
-	 * gets there (0.3 visits per step on text), LDS buys fragments per CU */
-	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 256u;
+	/* two 128-entry filters: a false alarm only costs a visit of the flagged lane when the chain
+	 * gets there (0.3 visits per step on text), and every KiB of LDS is worth ~4 % (one more
+	 * fragment per CU): 256 -> 128 entries costs 1 % at equal occupancy */
+	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 128u;
+	const uint32_t s_cap_hash = kn.s_entries ? kn.s_entries : 256u; /* (4 KiB pages: slot sharing is the rule) */
 	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
 	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
 	const uint32_t most = ((maxfrag / 2 + 63) & ~63u) + 64;
@@ -1856,7 +1881,7 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		P.tab = TAB_LDS_HASH; /* the dense table would be no smaller */
 	if (P.tab == TAB_LDS_HASH) {
 		P.lds0 = 1u << p;
-		filter_geometry(slots, s_cap, false, &P.s_entries, &P.s_shift);
+		filter_geometry(slots, s_cap_hash, false, &P.s_entries, &P.s_shift);
 		if (slots > P.s_entries) {
 			uint32_t bits = 0;
 			while ((1u << bits) < P.s_entries)
@@ -1871,6 +1896,14 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		filter_geometry(cap, s_cap, true, &P.s_entries, &P.s_shift);
 		P.fallback = (maxfrag > 3 && cap < (maxfrag - 3) / 2) || (kn.sample_min && maxfrag == kFragment);
 		P.sample_min = kn.sample_min;
+		/* fragments with more buckets than the first table get a second try with a larger one
+		 * (fewer fragments per CU) before the global table: URL lists sit at 4.5-5.5 k buckets */
+		if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
+			P.cap2 = kDenseCap2;
+			P.lds0_2 = 2 * P.cap2 > scratch ? 2 * P.cap2 : scratch;
+			filter_geometry(P.cap2, s_cap, true, &P.s_entries_2, &P.s_shift_2);
+			P.lds_bytes_2 = P.lds0_2 + P.s_entries_2 * 4 * (P.s_shift_2 ? 2 : 1);
+		}
 	}
 	/* global-table geometry (first launch when forced, else the fallback) */
 	P.g_lds0 = ((1u << p) >> 4) < 16 ? 16 : (1u << p) >> 4;
@@ -1895,6 +1928,8 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 			P.lds_bytes = pad;
 		if (pad > P.g_lds_bytes)
 			P.g_lds_bytes = pad;
+		if (P.cap2 && pad > P.lds_bytes_2)
+			P.lds_bytes_2 = pad;
 	}
 	return P;
 }
@@ -2054,6 +2089,10 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	     !hip_ok(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.g_lds_bytes),
 		     "hipFuncSetAttribute")))
 		return CSNAPPY_HIP_E_RUNTIME;
+	if (P.cap2 && P.lds_bytes_2 > P.lds_bytes &&
+	    !hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes_2),
+		    "hipFuncSetAttribute"))
+		return CSNAPPY_HIP_E_RUNTIME;
 
 	for (uint32_t b0 = 0; b0 < nblocks; b0 += W.chunk_blocks) {
 		const uint32_t nb = nblocks - b0 < W.chunk_blocks ? nblocks - b0 : W.chunk_blocks;
@@ -2068,6 +2107,19 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
 			    "launch snappy_parse_fragments"))
 			return CSNAPPY_HIP_E_RUNTIME;
+		if (P.cap2) {
+			A.lds0 = P.lds0_2;
+			A.s_entries = P.s_entries_2;
+			A.s_shift = P.s_shift_2;
+			A.dense_cap = P.cap2;
+			A.sample_min = 0;
+			A.only_unparsed = 1;
+			if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes_2, st),
+				    "launch snappy_parse_fragments (second table size)"))
+				return CSNAPPY_HIP_E_RUNTIME;
+			A.dense_cap = P.dense_cap;
+			A.sample_min = P.sample_min;
+		}
 		if (P.fallback) {
 			A.lds0 = P.g_lds0;
 			A.s_entries = P.g_s_entries;
