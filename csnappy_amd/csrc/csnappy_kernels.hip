@@ -100,8 +100,10 @@ DEVINL uint32_t rdlane(uint32_t v, uint32_t l)
  * state and drag it off the scalar unit) */
 DEVINL uint32_t common_prefix16(uint64_t xlo, uint64_t xhi)
 {
-	const uint32_t zl = (uint32_t)__ffsll((unsigned long long)xlo), zh = (uint32_t)__ffsll((unsigned long long)xhi);
-	return zl ? (zl - 1) >> 3 : zh ? 8u + ((zh - 1) >> 3) : 16u;
+	/* (the x ? ctz(x) : 64 form is what the compiler turns into v_ffbl + clamped add + min3) */
+	const uint32_t bl = xlo ? (uint32_t)__builtin_ctzll(xlo) : 64u;
+	const uint32_t bh = xhi ? (uint32_t)__builtin_ctzll(xhi) : 64u;
+	return (bl < 64u ? bl : 64u + bh) >> 3;
 }
 
 /* lanes whose predicate holds (the builtin takes the i1 itself: HIP's __ballot(int) makes the compiler
@@ -235,7 +237,6 @@ constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypa
 constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
-constexpr bool kTouchAhead = true;          /* parser: touch the input / id lines of the step after next */
 constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
 
 enum { TAB_LDS_HASH = 0, TAB_LDS_DENSE = 1, TAB_GLOBAL = 2 };
@@ -526,7 +527,6 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 		uint32_t p0, pos;
 		bool valid;
 		uint32_t raw[4], sid = kNoBucket;
-		uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
 		auto place = [&]() {
 			sparse = spec == 0 && qi >= 32;
 			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
@@ -553,18 +553,6 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			raw[2] = v.z;
 			raw[3] = v.w;
 			sid = idv;
-			/* touch what the step after this one will read (the cursor moves ~64 positions per
-			 * step), so that its loads find the lines in the cache; the values are not used */
-			asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
-			if (kTouchAhead && !sparse) {
-				const uint32_t q0 = min(pos + 64, n - 4), q1 = min(pos + 128, n - 4);
-				__builtin_memcpy(&pf0, src + q0, 4);
-				__builtin_memcpy(&pf1, src + q1, 4);
-				if (DENSE) {
-					pf2 = ids[q0];
-					pf3 = ids[q1];
-				}
-			}
 		};
 		place();
 		if (PROF)
@@ -600,20 +588,23 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			const uint32_t key = slot & smask;
 			const uint32_t key2 = DENSE ? ((slot >> A.s_shift) ^ (slot << (A.s_shift - 5))) & smask
 						    : (slot >> A.s_shift) & smask;
-			if (tabbed) {
-				atomicMin(&S[key], (epoch << 6) | lane);
-				if (A.s_shift)
-					atomicMin(&S2[key2], (epoch << 6) | lane);
-			}
+			/* (no branch on `tabbed`: a lane that takes no part offers the largest value) */
+			const uint32_t ftag = tabbed ? (epoch << 6) | lane : ~0u;
+			const bool two_filters = DENSE || A.s_shift != 0; /* (dense: always two) */
+			atomicMin(&S[key], ftag);
+			if (two_filters)
+				atomicMin(&S2[key2], ftag);
 			/* A lane that shares its slot with an earlier lane of the step ("flagged") cannot trust
 			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
 			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
 			uint32_t cand = 0, first_same;
-			if (!GTAB && tabbed)
-				cand = tab[slot];
+			if (!GTAB) {
+				cand = tab[tabbed ? slot : 0u];
+				cand = tabbed ? cand : 0u;
+			}
 			wave_lds_fence();
 			first_same = S[key] & 63u; /* lowest lane with my slot key */
-			if (A.s_shift)
+			if (two_filters)
 				first_same = max(first_same, S2[key2] & 63u);
 			const bool flagged = tabbed && first_same < lane;
 			uint64_t cmask = ballot64(flagged); /* flagged lanes */
@@ -627,10 +618,12 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				cand = tab[slot];
 			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
 			cand &= 0x7fffu;
-			cb[0] = cb[1] = cb[2] = cb[3] = 0;
-			if ((int)lane < ulim && maybe && !(GTAB && flagged)) {
-				uint4 w4; /* cand < pos, so these 16 bytes are inside the fragment too */
-				__builtin_memcpy(&w4, src + cand, 16);
+			/* the 16 bytes at the candidate (cand < pos: inside the fragment); lanes without one
+			 * read position 0 -- one broadcast line, cheaper than masking the load off */
+			const bool gathered = (int)lane < ulim && maybe && !(GTAB && flagged);
+			{
+				uint4 w4;
+				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
 				cb[0] = w4.x;
 				cb[1] = w4.y;
 				cb[2] = w4.z;
@@ -640,9 +633,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			 * 16 bytes away from every valid probe position) */
 			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
 			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
-			uint32_t mlen = common_prefix16(xlo, xhi);
-			if (!maybe || (GTAB && flagged))
-				mlen = 0; /* (nothing was gathered for a flagged lane of the global placement) */
+			uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
 			const uint64_t matchmask = ballot64((int)lane < ulim && mlen >= 4);
 			epoch--;
 			if (PROF) {
@@ -650,7 +641,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				t_vec += t1 - t0;
 			}
 
-			int e_final;            /* last lane whose table write is committed */
+			int e_final = 0;        /* last lane whose table write is committed */
 			bool inside = false;    /* dense: this lane lies strictly inside a taken copy */
 			uint64_t taken = 0;     /* dense: lanes whose match is part of the chain */
 			uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
@@ -1852,11 +1843,9 @@ void filter_geometry(uint32_t slots, uint32_t s_cap, bool dense, uint32_t *s_ent
 	uint32_t bits = 0;
 	while ((1u << bits) < *s_entries)
 		++bits;
-	/* a second filter on other bits of the slot when one filter cannot be exact */
-	if (slots <= *s_entries)
-		*s_shift = 0;
-	else
-		*s_shift = dense ? bits : (uint32_t)0;
+	/* a second filter on other bits of the slot when one filter cannot be exact (the dense parser
+	 * is compiled for two filters: it always gets both) */
+	*s_shift = dense ? bits : (uint32_t)0;
 }
 
 ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
