@@ -31,6 +31,12 @@ HIP_SYMBOLS = [
     "csnappy_workload_generate_host",
 ]
 
+FRAME_SYMBOLS = [
+    "csnappy_frame_max_compressed_length", "csnappy_frame_compress", "csnappy_frame_uncompressed_length",
+    "csnappy_frame_decompress", "csnappy_hip_crc32c_batch",
+]
+FRAME_E_NO_IDENTIFIER, FRAME_E_BAD_CHUNK, FRAME_E_CRC, FRAME_E_OUTPUT_INSUF, FRAME_E_DATA = -201, -202, -203, -204, -205
+
 _lib = None
 
 
@@ -82,6 +88,16 @@ def lib():
     L.csnappy_hip_get_kernel_timing.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.csnappy_hip_workload_generate.restype = i32
     L.csnappy_hip_workload_generate.argtypes = [i32, u64, u64, u32, u32, vp, vp]
+    L.csnappy_frame_max_compressed_length.restype = C.c_size_t
+    L.csnappy_frame_max_compressed_length.argtypes = [C.c_size_t]
+    L.csnappy_frame_compress.restype = i32
+    L.csnappy_frame_compress.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_size_t), i32]
+    L.csnappy_frame_uncompressed_length.restype = i32
+    L.csnappy_frame_uncompressed_length.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.csnappy_frame_decompress.restype = i32
+    L.csnappy_frame_decompress.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_size_t)]
+    L.csnappy_hip_crc32c_batch.restype = i32
+    L.csnappy_hip_crc32c_batch.argtypes = [vp, vp, vp, u32, vp, vp]
     L.csnappy_workload_generate_host.restype = None
     L.csnappy_workload_generate_host.argtypes = [i32, u64, u64, u32, u32, vp]
     _lib = L
@@ -160,6 +176,36 @@ def decompress_noheader(src, dst_cap):
     rc = lib().csnappy_decompress_noheader(src.ctypes.data if len(src) else None, len(src),
                                            dst.ctypes.data, C.byref(n))
     return rc, n.value, dst[:n.value if rc == 0 else 0].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# the framing format (include/csnappy_frame.h) on host buffers
+# ---------------------------------------------------------------------------------------------
+def frame_compress(data, p=16):
+    """-> (rc, framed bytes)"""
+    data = _u8(data)
+    cap = C.c_size_t(lib().csnappy_frame_max_compressed_length(len(data)))
+    out = np.empty(cap.value + 8, dtype=np.uint8)
+    rc = lib().csnappy_frame_compress(data.ctypes.data if len(data) else None, len(data), out.ctypes.data,
+                                      C.byref(cap), p)
+    return rc, out[:cap.value].tobytes() if rc == 0 else b""
+
+
+def frame_uncompressed_length(stream):
+    stream = _u8(stream)
+    r = C.c_size_t(0)
+    rc = lib().csnappy_frame_uncompressed_length(stream.ctypes.data if len(stream) else None, len(stream), C.byref(r))
+    return rc, r.value
+
+
+def frame_decompress(stream, dst_cap):
+    """-> (rc, bytes)"""
+    stream = _u8(stream)
+    dst = np.zeros(max(dst_cap, 1), dtype=np.uint8)
+    n = C.c_size_t(dst_cap)
+    rc = lib().csnappy_frame_decompress(stream.ctypes.data if len(stream) else None, len(stream), dst.ctypes.data,
+                                        C.byref(n))
+    return rc, dst[:n.value].tobytes() if rc == 0 else b""
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,330 @@
+/*
+ * csnappy_frame.c -- Snappy framing format (include/csnappy_frame.h) in plain C over the batch
+ * C-ABI.  The chunk walk is host code; the codec work (one 64 KiB STREAM block per data chunk)
+ * and the checksums (snappy_crc32c_blocks) run on the GPU, one batch launch each per call.
+ * There is no CPU codec here: without a HIP device the calls return CSNAPPY_FRAME_E_DEVICE.
+ *
+ * Spec followed: google/snappy framing_format.txt (sections 2-4); the reference tree holds no
+ * framing code (reference README:11-17 lists it as a goal only).
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/csnappy.h"
+#include "../../include/csnappy_frame.h"
+#include "../../include/csnappy_hip.h"
+
+static const unsigned char kStreamId[10] = { 0xff, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y' };
+#define SLOT 76544u /* >= csnappy_max_compressed_length(65536) = 76490, 64-byte multiple */
+
+struct dev {
+	void *p[8];
+	int n;
+};
+
+static void *dalloc(struct dev *d, size_t bytes)
+{
+	void *p = NULL;
+	if (d->n >= 8 || hipMalloc(&p, bytes ? bytes : 256) != hipSuccess)
+		return NULL;
+	d->p[d->n++] = p;
+	return p;
+}
+
+static void dfree(struct dev *d)
+{
+	while (d->n > 0)
+		(void)hipFree(d->p[--d->n]);
+}
+
+static uint32_t rd_le24(const unsigned char *p)
+{
+	return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+static uint32_t rd_le32(const unsigned char *p)
+{
+	return rd_le24(p) | ((uint32_t)p[3] << 24);
+}
+
+static void wr_chunk_header(unsigned char *q, unsigned type, uint32_t len, uint32_t crc)
+{
+	q[0] = (unsigned char)type;
+	q[1] = (unsigned char)len;
+	q[2] = (unsigned char)(len >> 8);
+	q[3] = (unsigned char)(len >> 16);
+	q[4] = (unsigned char)crc;
+	q[5] = (unsigned char)(crc >> 8);
+	q[6] = (unsigned char)(crc >> 16);
+	q[7] = (unsigned char)(crc >> 24);
+}
+
+size_t csnappy_frame_max_compressed_length(size_t n)
+{
+	const size_t chunks = (n + CSNAPPY_FRAME_CHUNK - 1) / CSNAPPY_FRAME_CHUNK;
+	return sizeof(kStreamId) + chunks * 8 + n;
+}
+
+int csnappy_frame_compress(const char *src, size_t n, char *dst, size_t *dst_len, int p)
+{
+	const size_t chunks = (n + CSNAPPY_FRAME_CHUNK - 1) / CSNAPPY_FRAME_CHUNK;
+	struct dev D = { { 0 }, 0 };
+	uint64_t *off = NULL;
+	uint32_t *len = NULL;
+	unsigned char *out = NULL, *q = (unsigned char *)dst;
+	size_t i, ws, need = sizeof(kStreamId);
+	int rc = CSNAPPY_FRAME_E_DEVICE;
+	void *d_in, *d_out, *d_off, *d_len, *d_ws;
+
+	if (p < 9 || p > 16 || chunks > 0x7fffffffu)
+		return CSNAPPY_FRAME_E_BAD_CHUNK;
+	if (*dst_len < sizeof(kStreamId))
+		return CSNAPPY_FRAME_E_OUTPUT_INSUF;
+	memcpy(q, kStreamId, sizeof(kStreamId));
+	if (chunks == 0) {
+		*dst_len = sizeof(kStreamId);
+		return CSNAPPY_FRAME_E_OK;
+	}
+	if (csnappy_hip_device_count() <= 0)
+		return CSNAPPY_FRAME_E_DEVICE;
+	/* descriptors: in_off | out_off (u64), in_len | out_len | crc (u32) */
+	off = malloc(2 * chunks * sizeof(uint64_t));
+	len = malloc(3 * chunks * sizeof(uint32_t));
+	out = malloc(chunks * (size_t)SLOT);
+	if (!off || !len || !out)
+		goto done;
+	for (i = 0; i < chunks; i++) {
+		off[i] = (uint64_t)i * CSNAPPY_FRAME_CHUNK;
+		off[chunks + i] = (uint64_t)i * SLOT;
+		len[i] = (uint32_t)(n - i * CSNAPPY_FRAME_CHUNK < CSNAPPY_FRAME_CHUNK ? n - i * CSNAPPY_FRAME_CHUNK
+										       : CSNAPPY_FRAME_CHUNK);
+	}
+	ws = csnappy_hip_compress_workspace_size((uint32_t)chunks, CSNAPPY_FRAME_CHUNK);
+	d_in = dalloc(&D, n + 64);
+	d_out = dalloc(&D, chunks * (size_t)SLOT);
+	d_off = dalloc(&D, 2 * chunks * sizeof(uint64_t));
+	d_len = dalloc(&D, 3 * chunks * sizeof(uint32_t));
+	d_ws = dalloc(&D, ws);
+	if (!d_in || !d_out || !d_off || !d_len || !d_ws)
+		goto done;
+	if (hipMemcpy(d_in, src, n, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_off, off, 2 * chunks * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_len, len, chunks * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+		goto done;
+	/* all chunks: one compress batch (each chunk = one csnappy_compress block) + one CRC batch */
+	if (csnappy_hip_compress_batch(d_in, (uint64_t *)d_off, (uint32_t *)d_len, (uint32_t)chunks,
+				       CSNAPPY_FRAME_CHUNK, d_out, (uint64_t *)d_off + chunks,
+				       (uint32_t *)d_len + chunks, p, CSNAPPY_HIP_STREAM, d_ws, ws, NULL) ||
+	    csnappy_hip_crc32c_batch(d_in, (uint64_t *)d_off, (uint32_t *)d_len, (uint32_t)chunks,
+				     (uint32_t *)d_len + 2 * chunks, NULL))
+		goto done;
+	if (hipDeviceSynchronize() != hipSuccess ||
+	    hipMemcpy(len + chunks, (uint32_t *)d_len + chunks, 2 * chunks * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+	    hipMemcpy(out, d_out, chunks * (size_t)SLOT, hipMemcpyDeviceToHost) != hipSuccess)
+		goto done;
+	/* assemble: a chunk is stored compressed only when that is smaller */
+	for (i = 0; i < chunks; i++) {
+		const uint32_t ilen = len[i], olen = len[chunks + i], crc = len[2 * chunks + i];
+		const int comp = olen < ilen;
+		const uint32_t body = comp ? olen : ilen;
+		need += 8 + (size_t)body;
+		if (need > *dst_len) {
+			rc = CSNAPPY_FRAME_E_OUTPUT_INSUF;
+			goto done;
+		}
+		q = (unsigned char *)dst + need - 8 - body;
+		wr_chunk_header(q, comp ? 0x00 : 0x01, 4 + body, crc);
+		memcpy(q + 8, comp ? out + i * (size_t)SLOT : (const unsigned char *)src + off[i], body);
+	}
+	*dst_len = need;
+	rc = CSNAPPY_FRAME_E_OK;
+done:
+	dfree(&D);
+	free(off);
+	free(len);
+	free(out);
+	return rc;
+}
+
+/* One data chunk found by the walk. */
+struct piece {
+	uint64_t src_off;  /* body (compressed block, or raw bytes) in the stream */
+	uint32_t src_len;
+	uint32_t ulen;     /* uncompressed bytes */
+	uint32_t crc;      /* masked CRC stored in the chunk */
+	int compressed;
+};
+
+/* Walks a framed stream; calls back for every data chunk.  Returns 0 or a CSNAPPY_FRAME_E_ code. */
+static int walk(const unsigned char *s, size_t n, struct piece **pieces, size_t *npieces, size_t *total)
+{
+	size_t pos = 0, cap = 0, cnt = 0, sum = 0;
+	struct piece *v = NULL;
+	if (n < sizeof(kStreamId) || memcmp(s, kStreamId, sizeof(kStreamId)))
+		return CSNAPPY_FRAME_E_NO_IDENTIFIER;
+	while (pos < n) {
+		unsigned type;
+		uint32_t len;
+		const unsigned char *d;
+		if (n - pos < 4)
+			goto bad;
+		type = s[pos];
+		len = rd_le24(s + pos + 1);
+		if (n - pos - 4 < len)
+			goto bad;
+		d = s + pos + 4;
+		pos += 4 + (size_t)len;
+		if (type == 0xff) {
+			if (len != 6 || memcmp(d, kStreamId + 4, 6))
+				goto bad;
+			continue;
+		}
+		if (type >= 0x80)
+			continue; /* padding (0xfe) and reserved skippable chunks */
+		if (type > 0x01)
+			goto bad; /* reserved unskippable */
+		if (len < 4)
+			goto bad;
+		if (cnt == cap) {
+			struct piece *nv = realloc(v, (cap = cap ? 2 * cap : 64) * sizeof(*v));
+			if (!nv)
+				goto bad;
+			v = nv;
+		}
+		v[cnt].crc = rd_le32(d);
+		v[cnt].src_off = (uint64_t)(d + 4 - s);
+		v[cnt].src_len = len - 4;
+		v[cnt].compressed = type == 0x00;
+		if (type == 0x00) {
+			uint32_t ulen = 0;
+			if (csnappy_get_uncompressed_length((const char *)d + 4, len - 4, &ulen) < 0)
+				goto bad;
+			v[cnt].ulen = ulen;
+		} else {
+			v[cnt].ulen = len - 4;
+		}
+		if (v[cnt].ulen > CSNAPPY_FRAME_CHUNK)
+			goto bad; /* framing_format.txt 4.2 / 4.3: at most 65536 uncompressed bytes */
+		sum += v[cnt].ulen;
+		cnt++;
+	}
+	*pieces = v;
+	*npieces = cnt;
+	*total = sum;
+	return CSNAPPY_FRAME_E_OK;
+bad:
+	free(v);
+	return CSNAPPY_FRAME_E_BAD_CHUNK;
+}
+
+int csnappy_frame_uncompressed_length(const char *src, size_t n, size_t *result)
+{
+	struct piece *v = NULL;
+	size_t cnt = 0;
+	int rc = walk((const unsigned char *)src, n, &v, &cnt, result);
+	if (rc == CSNAPPY_FRAME_E_OK)
+		free(v);
+	return rc;
+}
+
+int csnappy_frame_decompress(const char *src, size_t n, char *dst, size_t *dst_len)
+{
+	struct piece *v = NULL;
+	size_t cnt = 0, total = 0, i, nc = 0, nr = 0, pos;
+	struct dev D = { { 0 }, 0 };
+	uint64_t *off = NULL;
+	uint32_t *u32 = NULL;
+	int rc = walk((const unsigned char *)src, n, &v, &cnt, &total);
+	void *d_src, *d_out, *d_off, *d_u32;
+
+	if (rc != CSNAPPY_FRAME_E_OK)
+		return rc;
+	if (total > *dst_len) {
+		free(v);
+		return CSNAPPY_FRAME_E_OUTPUT_INSUF;
+	}
+	if (cnt == 0) {
+		free(v);
+		*dst_len = 0;
+		return CSNAPPY_FRAME_E_OK;
+	}
+	rc = CSNAPPY_FRAME_E_DEVICE;
+	if (cnt > 0x7fffffffu || csnappy_hip_device_count() <= 0)
+		goto done;
+	for (i = 0; i < cnt; i++)
+		if (v[i].compressed)
+			nc++;
+	nr = cnt - nc;
+	/* descriptors.  Compressed chunks first (decompress batch + CRC over the output), raw chunks
+	 * after them (CRC over the stream bytes):
+	 *   off: [0,cnt) input offsets (into the stream), [cnt,2cnt) output offsets
+	 *   u32: [0,cnt) input lengths, [cnt,2cnt) uncompressed lengths (= out_cap),
+	 *        [2cnt,3cnt) status, [3cnt,4cnt) produced, [4cnt,5cnt) computed masked CRCs */
+	off = malloc(2 * cnt * sizeof(uint64_t));
+	u32 = malloc(5 * cnt * sizeof(uint32_t));
+	if (!off || !u32)
+		goto done;
+	{
+		size_t ic = 0, ir = nc;
+		for (i = 0, pos = 0; i < cnt; i++) {
+			const size_t k = v[i].compressed ? ic++ : ir++;
+			off[k] = v[i].src_off;
+			off[cnt + k] = pos;
+			u32[k] = v[i].src_len;
+			u32[cnt + k] = v[i].ulen;
+			pos += v[i].ulen;
+		}
+	}
+	d_src = dalloc(&D, n + 64);
+	d_out = dalloc(&D, total + 64);
+	d_off = dalloc(&D, 2 * cnt * sizeof(uint64_t));
+	d_u32 = dalloc(&D, 5 * cnt * sizeof(uint32_t));
+	if (!d_src || !d_out || !d_off || !d_u32)
+		goto done;
+	if (hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_off, off, 2 * cnt * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_u32, u32, 2 * cnt * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+		goto done;
+	if (nc && (csnappy_hip_decompress_batch(d_src, (uint64_t *)d_off, (uint32_t *)d_u32, (uint32_t)nc, d_out,
+						(uint64_t *)d_off + cnt, (uint32_t *)d_u32 + cnt,
+						(int32_t *)((uint32_t *)d_u32 + 2 * cnt), (uint32_t *)d_u32 + 3 * cnt,
+						CSNAPPY_HIP_STREAM, NULL) ||
+		   csnappy_hip_crc32c_batch(d_out, (uint64_t *)d_off + cnt, (uint32_t *)d_u32 + cnt, (uint32_t)nc,
+					    (uint32_t *)d_u32 + 4 * cnt, NULL)))
+		goto done;
+	if (nr && csnappy_hip_crc32c_batch(d_src, (uint64_t *)d_off + nc, (uint32_t *)d_u32 + nc, (uint32_t)nr,
+					   (uint32_t *)d_u32 + 4 * cnt + nc, NULL))
+		goto done;
+	if (hipDeviceSynchronize() != hipSuccess ||
+	    hipMemcpy(u32 + 2 * cnt, (uint32_t *)d_u32 + 2 * cnt, 3 * cnt * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+	    (total && hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost) != hipSuccess))
+		goto done;
+	{
+		size_t ic = 0, ir = nc;
+		for (i = 0; i < cnt; i++) {
+			const size_t k = v[i].compressed ? ic++ : ir++;
+			if (v[i].compressed) {
+				if ((int32_t)u32[2 * cnt + k] != CSNAPPY_E_OK || u32[3 * cnt + k] != v[i].ulen) {
+					rc = CSNAPPY_FRAME_E_DATA;
+					goto done;
+				}
+			} else {
+				memcpy(dst + off[cnt + k], src + v[i].src_off, v[i].ulen);
+			}
+			if (u32[4 * cnt + k] != v[i].crc) {
+				rc = CSNAPPY_FRAME_E_CRC;
+				goto done;
+			}
+		}
+	}
+	*dst_len = total;
+	rc = CSNAPPY_FRAME_E_OK;
+done:
+	dfree(&D);
+	free(off);
+	free(u32);
+	free(v);
+	return rc;
+}

@@ -40,6 +40,7 @@
 
 #include "../../include/csnappy.h"
 #include "../../include/csnappy_hip.h"
+#include "../../include/csnappy_frame.h"
 #include "workload_gen.h"
 
 namespace {
@@ -1683,6 +1684,65 @@ snappy_compact_stream(const uint8_t *out, const uint64_t *out_off, const uint32_
 }
 
 /* ==========================================================================================
+ * CRC-32C of byte ranges (Snappy framing format, include/csnappy_frame.h): one wave per range.
+ * Every lane runs the byte-wise table CRC over its 1/64th of the range; the 64 partial CRCs are
+ * combined with crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B)  (the standard combine rule for
+ * finalised CRCs; reflected polynomial 0x82F63B78, RFC 3720).
+ * ======================================================================================== */
+constexpr uint32_t kCrc32cPoly = 0x82F63B78u;
+
+/* a(x) * b(x) mod P, reflected bit order (bit 31 = x^0) */
+DEVINL uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+	uint32_t p = 0;
+	for (uint32_t m = 0x80000000u; m; m >>= 1) {
+		if (a & m)
+			p ^= b;
+		b = (b & 1u) ? (b >> 1) ^ kCrc32cPoly : b >> 1;
+	}
+	return p;
+}
+
+struct CrcArgs {
+	const uint8_t *data;
+	const uint64_t *off;
+	const uint32_t *len;
+	uint32_t *crc;
+	uint32_t x2n[32]; /* x^(2^k) mod P */
+};
+
+extern "C" __global__ void __launch_bounds__(64) snappy_crc32c_blocks(CrcArgs A)
+{
+	__shared__ uint32_t T[256];
+	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+	for (uint32_t b = lane; b < 256; b += 64) {
+		uint32_t c = b;
+		for (int k = 0; k < 8; ++k)
+			c = (c & 1u) ? (c >> 1) ^ kCrc32cPoly : c >> 1;
+		T[b] = c;
+	}
+	wave_lds_fence();
+	const uint8_t *s = A.data + A.off[blk];
+	const uint32_t n = A.len[blk];
+	const uint32_t seg = (n + 63) / 64;
+	const uint32_t lo = min(n, lane * seg), hi = min(n, lo + seg);
+	uint32_t c = ~0u;
+	for (uint32_t i = lo; i < hi; ++i)
+		c = T[(c ^ s[i]) & 0xffu] ^ (c >> 8);
+	c = ~c; /* the finalised CRC of my segment (0 for an empty one) */
+	/* shift by the bytes behind my segment: x^(8 * after) by square-and-multiply */
+	uint32_t after = n - hi, op = 0x80000000u; /* x^0 */
+	for (uint32_t k = 3; after; after >>= 1, ++k)
+		if (after & 1u)
+			op = crc_mulmod(A.x2n[k & 31], op);
+	c = crc_mulmod(op, c);
+	for (int d = 32; d; d >>= 1)
+		c ^= (uint32_t)__shfl_xor((int)c, d, 64);
+	if (lane == 0)
+		A.crc[blk] = ((c >> 15) | (c << 17)) + 0xa282ead8u; /* masked, framing_format.txt section 3 */
+}
+
+/* ==========================================================================================
  * workload generator kernel (bench/test input; see workload_gen.h)
  * ======================================================================================== */
 extern "C" __global__ void __launch_bounds__(64)
@@ -2170,6 +2230,37 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
 			   static_cast<hipStream_t>(stream), static_cast<const uint8_t *>(d_out), d_out_off,
 			   d_out_len, d_dense_off, static_cast<uint8_t *>(d_dense));
 	if (!hip_ok(hipGetLastError(), "launch snappy_compact_stream"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	return 0;
+}
+
+int csnappy_hip_crc32c_batch(const void *d_data, const uint64_t *d_off, const uint32_t *d_len,
+			     uint32_t nblocks, uint32_t *d_crc, void *stream)
+{
+	if (nblocks == 0)
+		return 0;
+	CrcArgs A;
+	A.data = static_cast<const uint8_t *>(d_data);
+	A.off = d_off;
+	A.len = d_len;
+	A.crc = d_crc;
+	/* x^(2^k) mod P by repeated squaring on the host (reflected: bit 31 = x^0, bit 30 = x^1) */
+	auto mulmod = [](uint32_t a, uint32_t b) {
+		uint32_t p = 0;
+		for (uint32_t m = 0x80000000u; m; m >>= 1) {
+			if (a & m)
+				p ^= b;
+			b = (b & 1u) ? (b >> 1) ^ 0x82F63B78u : b >> 1;
+		}
+		return p;
+	};
+	uint32_t v = 0x40000000u;
+	for (int k = 0; k < 32; ++k) {
+		A.x2n[k] = v;
+		v = mulmod(v, v);
+	}
+	hipLaunchKernelGGL(snappy_crc32c_blocks, dim3(nblocks), dim3(64), 0, static_cast<hipStream_t>(stream), A);
+	if (!hip_ok(hipGetLastError(), "launch snappy_crc32c_blocks"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	return 0;
 }

@@ -23,15 +23,16 @@ def declared(header):
 def test_headers_declare_what_the_binding_lists():
     assert declared("csnappy.h") == sorted(api.LEGACY_SYMBOLS)
     assert declared("csnappy_hip.h") == sorted(api.HIP_SYMBOLS)
+    assert declared("csnappy_frame.h") == sorted(api.FRAME_SYMBOLS)
 
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = api.lib()
-    for name in api.LEGACY_SYMBOLS + api.HIP_SYMBOLS:
+    for name in api.LEGACY_SYMBOLS + api.HIP_SYMBOLS + api.FRAME_SYMBOLS:
         assert hasattr(L, name), name
     out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
-    assert set(api.LEGACY_SYMBOLS + api.HIP_SYMBOLS) <= exported
+    assert set(api.LEGACY_SYMBOLS + api.HIP_SYMBOLS + api.FRAME_SYMBOLS) <= exported
     # the code object for gfx950 is embedded
     blob = open(api.LIB_PATH, "rb").read()
     assert b"gfx950" in blob

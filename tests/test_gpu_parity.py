@@ -680,3 +680,84 @@ def test_bench_prints_one_json_line_with_the_contract_fields(torch):
     assert d["value"] > 0
     kt = sum(v["ms_per_step"] for v in d["kernels"].values())
     assert 0.5 * d["ms_per_step"] <= kt <= 1.05 * d["ms_per_step"], (kt, d["ms_per_step"])
+
+
+# -------------------------------------------------------------------------------------------------
+# next-row f4: the Snappy framing format (include/csnappy_frame.h) on the batch path
+# -------------------------------------------------------------------------------------------------
+def _frame_oracle():
+    from oracle import frame
+    P = oracle.Port()
+    return frame, (lambda x, p=16: P.compress(x, p)), (lambda b, n: P.decompress(b, n)), (lambda b: P.get_uncompressed_length(b))
+
+
+def test_framing_crc32c_batch_on_the_device(torch):
+    """snappy_crc32c_blocks: masked CRC-32C of ragged byte ranges (0 .. 70000 bytes, any alignment)
+    against the spec restatement; includes the RFC 3720 known answers."""
+    frame, _, _, _ = _frame_oracle()
+    rng = np.random.default_rng(5)
+    parts = [b"123456789", bytes(32), b"\xff" * 32, bytes(range(32)), b"", b"a"]
+    parts += [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in (1, 63, 64, 65, 127, 4097, 65535, 65536, 70000)]
+    lens = np.array([len(x) for x in parts], dtype=np.uint32)
+    off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64) + 3  # odd base
+    blob = np.frombuffer(b"\0\0\0" + b"".join(parts) + b"\0" * 16, dtype=np.uint8).copy()
+    d = torch.from_numpy(blob).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(lens.astype(np.int32)).cuda()
+    d_crc = torch.zeros(len(parts), dtype=torch.int32, device="cuda")
+    rc = api.lib().csnappy_hip_crc32c_batch(d.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), len(parts),
+                                            d_crc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    got = d_crc.cpu().numpy().astype(np.uint32).tolist()
+    assert got == [frame.mask(frame.crc32c(x)) for x in parts]
+
+
+@pytest.mark.parametrize("p", [16, 13])
+def test_framing_writer_and_reader_against_the_spec_restatement(torch, urls, p):
+    """csnappy_frame_compress gives byte for byte what the spec restatement assembles from the
+    reference-equivalent block encoder (same chunking, same compressed-or-raw rule), for sizes
+    around the chunk limit and mixed content; csnappy_frame_decompress returns the input and
+    also reads streams with padding / skippable / repeated-identifier chunks."""
+    frame, comp, dec, ulen = _frame_oracle()
+    rng = np.random.default_rng(11)
+    cases = [b"", b"a", b"abc", urls[:65535], urls[:65536], urls[:65537], urls[:300000],
+             bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),          # incompressible: raw chunks
+             urls[:70000] + bytes(rng.integers(0, 256, 70000, dtype=np.uint8)) + bytes(200000)]
+    for x in cases:
+        want = frame.encode(x, lambda c: comp(c, p))
+        rc, got = api.frame_compress(x, p)
+        assert rc == 0 and got == want, (len(x), rc, len(got), len(want))
+        assert len(got) <= api.lib().csnappy_frame_max_compressed_length(len(x))
+        assert api.frame_uncompressed_length(got) == (0, len(x))
+        assert api.frame_decompress(got, len(x)) == (0, x)
+        # chunks a reader must skip, in front of, between and behind the data chunks
+        if len(got) > 10:
+            cut = 10 + 4 + int.from_bytes(got[11:14], "little")
+            g = got[:10] + b"\xfe\x05\x00\x00hello" + got[10:cut] + b"\x99\x00\x00\x00" + got[:10] + got[cut:] + b"\xfe\x00\x00\x00"
+            assert frame.decode(g, dec, ulen) == (0, x)
+            assert api.frame_decompress(g, len(x) + 5) == (0, x)
+
+
+def test_framing_reader_rejects_what_the_spec_rejects(torch, urls):
+    frame, comp, dec, ulen = _frame_oracle()
+    x = urls[:150000]
+    f = frame.encode(x, comp)
+    raw = frame.encode(b"\x00\x01\x02" * 5, comp)  # one uncompressed chunk
+    bad_crc, bad_crc_raw = bytearray(f), bytearray(raw)
+    bad_crc[15] ^= 0x40
+    bad_crc_raw[16] ^= 0x01
+    damaged = bytearray(f)
+    damaged[30] ^= 0xFF   # inside the first Snappy block: malformed data or a checksum mismatch
+    big = f[:10] + b"\x01" + (4 + 65537).to_bytes(3, "little") + bytes(4 + 65537)
+    vectors = [(f[10:], len(x)), (b"", 10), (f[:9], 10), (f[:10] + b"\x7f\x00\x00\x00" + f[10:], len(x)),
+               (f[:-3], len(x)), (f[:10] + b"\x00\x02\x00\x00ab", 10), (f[:10] + b"\xff\x06\x00\x00sNaPpX", 10),
+               (bytes(bad_crc), len(x)), (bytes(bad_crc_raw), 64), (bytes(damaged), len(x)), (big, 70000),
+               (f, len(x) - 1), (f, 0)]
+    for s, cap in vectors:
+        want_rc, want = frame.decode(s, dec, ulen, dst_cap=cap)
+        rc, got = api.frame_decompress(s, cap)
+        assert rc == want_rc, (s[:24].hex(), cap, rc, want_rc)
+        assert want_rc != 0 or got == want
+    assert {frame.decode(s, dec, ulen, dst_cap=c)[0] for s, c in vectors} >= {frame.E_NO_IDENTIFIER, frame.E_BAD_CHUNK,
+                                                                             frame.E_CRC, frame.E_OUTPUT_INSUF}
