@@ -1468,6 +1468,8 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, 
 		d[o1] = p1;
 }
 
+constexpr uint32_t kOutStage = 2048; /* bytes of a batch's output assembled in LDS */
+
 extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(DecompressArgs A)
 {
 	/* 32-bit cursors: in_len and out_cap are uint32 in the reference API too; the batch API asks
@@ -1516,70 +1518,92 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	}
 
 	uint32_t op = 0;        /* bytes produced */
-	uint64_t next8 = 0;     /* the 8 input bytes at the next iteration's ip + lane */
+	uint64_t next8 = 0;     /* the 8 input bytes at the next scan iteration's ip + lane */
 	bool have_next = false; /* ... valid for every lane */
-	while (status == CSNAPPY_E_OK && ip < n) {
-		/* ---- every lane decodes the byte at ip+lane as if it were a tag ----
-		 * (the 8 bytes were requested at the end of the previous iteration when possible) */
-		const uint32_t at = ip + lane;
-		uint32_t b0 = 0, tr = 0;
-		if (have_next) {
-			b0 = (uint32_t)next8 & 0xff;
-			tr = (uint32_t)(next8 >> 8);
-		} else if (at + 8 <= n) {
-			uint64_t v;
-			__builtin_memcpy(&v, src + at, 8);
-			b0 = (uint32_t)v & 0xff;
-			tr = (uint32_t)(v >> 8);
-			asm volatile("" : "+v"(b0), "+v"(tr)); /* wait here, not where the paths join */
-		} else {
-			if (at < n)
-				b0 = src[at];
+	/* queue of decoded elements between the two phases: {tag position, length, offset, header
+	 * size | literal << 3}, a ring of 128 (a scan iteration adds at most 64) */
+	__shared__ uint4 queue[128];
+	__shared__ __attribute__((aligned(16))) uint8_t ostage[kOutStage + 16 + 64];
+	uint32_t qh = 0, qn = 0;
+	const uint64_t lt_mask = (1ull << lane) - 1;
+	while (status == CSNAPPY_E_OK) {
+		/* ================= phase 1: scan -- find the real tags, queue what they decode to ======
+		 * Every lane decodes the byte at ip+lane as if it were a tag (one LDS load of the
+		 * reference's char_table entry, csnappy_decompress.c:152-185: bits 0-6 length, 7-9 extra
+		 * bytes, 10-12 offset bits 8..10 of a 1-byte-offset copy, 13 literal; then :348-365 as
+		 * selects), the true tag chain is walked on the scalar unit (five instructions per tag),
+		 * and only the lanes on it write an element.  (Scanning one byte per lane and decoding
+		 * only the real tags in phase 2 was tried: fewer instructions, but one more dependent
+		 * global round trip per batch -- 2.41 -> 2.85 ms per GiB of text.) */
+		while (qn < 64 && ip < n) {
+			const uint32_t at = ip + lane;
+			uint32_t b0 = 0, tr = 0;
+			if (have_next) {
+				b0 = (uint32_t)next8 & 0xff;
+				tr = (uint32_t)(next8 >> 8);
+			} else if (at + 8 <= n) {
+				uint64_t v;
+				__builtin_memcpy(&v, src + at, 8);
+				b0 = (uint32_t)v & 0xff;
+				tr = (uint32_t)(v >> 8);
+				asm volatile("" : "+v"(b0), "+v"(tr)); /* wait here, not where the paths join */
+			} else {
+				if (at < n)
+					b0 = src[at];
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
-				if (at + 1 + k < n)
-					tr |= (uint32_t)src[at + 1 + k] << (8 * k);
-			asm volatile("" : "+v"(b0), "+v"(tr));
+				for (int kk = 0; kk < 4; ++kk)
+					if (at + 1 + kk < n)
+						tr |= (uint32_t)src[at + 1 + kk] << (8 * kk);
+				asm volatile("" : "+v"(b0), "+v"(tr));
+			}
+			const uint32_t e = ctab[b0];
+			const uint32_t extra = (e >> 7) & 7u;
+			const bool is_lit = (e >> 13) & 1u;
+			const uint32_t xmask = 0xffffffffu >> ((32u - 8u * extra) & 31u); /* extra 0 -> all ones (unused) */
+			const uint32_t trm = tr & xmask;
+			const uint32_t l = (is_lit && extra != 0) ? trm + 1 : (e & 127u);
+			const uint32_t off = is_lit ? 0u : trm | (((e >> 10) & 7u) << 8);
+			const uint32_t hsz = 1 + extra;
+			/* bytes this element takes in the input (a literal length that would wrap 32 bits is
+			 * negative as int32 and fails in phase 2 whatever the walk does after it) */
+			const uint32_t esz = is_lit ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
+			uint64_t tmask = 0;
+			uint32_t cur = 0;
+			const uint32_t room = n - ip; /* > 0 */
+			const uint32_t wlim = min(64u, room);
+			const uint32_t nxt = lane + esz < lane ? 0xffffffffu : lane + esz; /* next tag if I am one */
+			do {
+				tmask |= 1ull << cur;
+				cur = rdlane(nxt, cur);
+			} while (cur < wlim);
+			/* request the next iteration's bytes now */
+			have_next = cur < room && room - cur >= 64 + 8;
+			if (have_next)
+				__builtin_memcpy(&next8, src + (ip + cur + lane), 8);
+			if ((tmask >> lane) & 1) {
+				const uint32_t r = (uint32_t)__builtin_popcountll(tmask & lt_mask);
+				queue[(qh + qn + r) & 127u] = make_uint4(at, l, off, hsz | (is_lit ? 8u : 0u));
+			}
+			qn += (uint32_t)__builtin_popcountll(tmask);
+			ip = cur >= room ? n : ip + cur;
 		}
-		/* one LDS load of the reference's char_table entry (csnappy_decompress.c:152-185, here:
-		 * bits 0-6 length, 7-9 extra bytes, 10-12 offset bits 8..10 of a 1-byte-offset copy,
-		 * 13 literal), then what the reference does with it (:348-365) as selects */
-		const uint32_t e = ctab[b0];
-		const uint32_t extra = (e >> 7) & 7u;
-		const bool is_lit = (e >> 13) & 1u;
-		const uint32_t kind = is_lit ? 0u : 1u; /* only "literal or copy" matters below */
-		const uint32_t xmask = 0xffffffffu >> ((32u - 8u * extra) & 31u); /* extra 0 -> all ones (unused) */
-		const uint32_t trm = tr & xmask;
-		const uint32_t l = (is_lit && extra != 0) ? trm + 1 : (e & 127u);
-		const uint32_t off = is_lit ? 0u : trm | (((e >> 10) & 7u) << 8);
-		const uint32_t hsz = 1 + extra;
-		/* bytes this element takes in the input (a literal length that would wrap 32 bits is
-		 * negative as int32 and fails below whatever the walk does after it) */
-		const uint32_t esz = is_lit ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
-
-		/* ---- walk the real tag chain on the scalar unit ---- */
-		uint64_t tmask = 0;
-		uint32_t cur = 0;
-		const uint32_t room = n - ip; /* > 0 */
-		const uint32_t wlim = min(64u, room);
-		const uint32_t nxt = lane + esz < lane ? 0xffffffffu : lane + esz; /* next tag if I am one */
-		do {
-			tmask |= 1ull << cur;
-			cur = rdlane(nxt, cur);
-		} while (cur < wlim);
-		const bool istag = (tmask >> lane) & 1;
-		/* request the next iteration's bytes now; they arrive while this one's copies run */
-		have_next = cur < room && room - cur >= 64 + 8;
-		if (have_next)
-			__builtin_memcpy(&next8, src + (ip + cur + lane), 8);
-
+		if (qn == 0)
+			break;
+		wave_lds_fence();
+		/* ================= phase 2: execute up to 64 elements, one lane each ===================== */
+		const uint32_t m = min(qn, 64u);
+		const bool live = lane < m;
+		const uint4 q = queue[(qh + lane) & 127u];
+		wave_lds_fence();
+		const uint32_t at = q.x, l = live ? q.y : 0u, off = q.z, hsz = q.w & 7u;
+		const bool is_lit = (q.w >> 3) & 1u;
 		/* ---- per-element checks, in the reference's order (Appendix C of SURVEY.md) ---- */
 		const bool trunc = at + hsz > n; /* header bytes cut off: reference is undefined, we say -5 */
 		const uint32_t avail = trunc ? 0 : n - (at + hsz);
-		const bool lit_short = kind == 0 && (int32_t)l >= 0 && avail < l; /* :374-375 */
-		const bool lit_neg = kind == 0 && (int32_t)l < 0;
+		const bool lit_short = is_lit && (int32_t)l >= 0 && avail < l; /* :374-375 */
+		const bool lit_neg = is_lit && (int32_t)l < 0;
 		const bool inbad = trunc || lit_short || lit_neg;
-		const uint32_t eff = (istag && !inbad) ? l : 0;
+		const uint32_t eff = (live && !inbad) ? l : 0;
 		const uint32_t excl = wave_incl_scan_dpp(eff) - eff;
 		const uint32_t pb = op + excl; /* bytes produced before this element */
 		/* literal: short input (-5), then output overrun (-3, :288-289, :274-275), then a length
@@ -1590,63 +1614,116 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const int32_t err_tag = first5 ? CSNAPPY_E_DATA_MALFORMED
 				      : overrun ? CSNAPPY_E_OUTPUT_OVERRUN
 				      : lit_neg ? CSNAPPY_E_DATA_MALFORMED : 0;
-		const int32_t err = istag ? err_tag : 0;
+		const int32_t err = live ? err_tag : 0;
 		const uint64_t emask = ballot64(err != 0);
 		const uint32_t fe = emask ? first_lane(emask) : 64;
-		const uint64_t run = fe < 64 ? (tmask & ((1ull << fe) - 1)) : tmask; /* elements to execute */
+		const uint64_t livemask = m < 64 ? (1ull << m) - 1 : ~0ull;
+		const uint64_t run = fe < 64 ? (livemask & ((1ull << fe) - 1)) : livemask; /* elements to execute */
 		const bool exec_me = (run >> lane) & 1;
 
-		/* ---- passes 1+2 in one sweep, one lane per element: literals (SAW__Append /
-		 * SAW__AppendFastPath, :264-293) and copies that read only what earlier batches produced
-		 * (source ends in front of this batch's output) ---- */
-		const uint8_t *lsrc = src + (at + hsz);
-		uint8_t *edst = dst + pb;
-		const bool lit = exec_me && kind == 0;
-		const bool cpy = exec_me && kind != 0;
-		const bool indep = cpy && off >= excl + l;
-		copy_exact(edst, lit ? lsrc : edst - off, l, (lit && l <= 64) || indep, next8);
-		for (uint64_t big = ballot64(lit && l > 64); big; big &= big - 1) {
-			const uint32_t t = first_lane(big);
-			const uint32_t L = rdlane(l, t);
-			const uint8_t *ps = src + (ip + t + rdlane(hsz, t));
-			uint8_t *pd = dst + (op + rdlane(excl, t));
-			/* long literal: 4 x 16 B per lane per iteration (unaligned vector accesses; the four
-			 * loads are issued before the first store so that one round trip moves 4 KiB), byte
-			 * tail */
+		/* The batch's output is assembled in LDS and flushed with aligned 16 B/lane stores: copies
+		 * whose source lies inside the batch (most short-distance copies, with 64 elements per
+		 * batch) then cost an LDS round trip each instead of an HBM one.  nfit = leading elements
+		 * whose output fits the staging; staged byte t is output byte op + t and sits at
+		 * ostage[sa + t], sa = (dst + op) & 15, so LDS 16 B chunks line up with global ones. */
+		const uint32_t nrun = fe < 64 ? fe : m;
+		const uint64_t fitmask = ballot64(exec_me && excl + l <= kOutStage);
+		const uint32_t nfit = ~fitmask ? first_lane(~fitmask) : 64u;
+		if (nfit == 0 && nrun > 0) {
+			/* the first element does not fit: a long literal (copies are <= 64 bytes).  4 x 16 B per
+			 * lane per iteration straight to HBM (the four loads are issued before the first store
+			 * so that one round trip moves 4 KiB), byte tail */
+			const uint32_t L = rdlane(l, 0);
+			const uint8_t *ps = src + (rdlane(at, 0) + rdlane(hsz, 0));
+			uint8_t *pd = dst + op;
 			const uint32_t body = L & ~15u;
 			for (uint32_t j0 = lane * 16; j0 < body; j0 += 4096) {
 				uint4 v[4];
 #pragma unroll
-				for (int k = 0; k < 4; ++k)
-					if (j0 + 1024u * k < body)
-						__builtin_memcpy(&v[k], ps + j0 + 1024u * k, 16);
+				for (int kk = 0; kk < 4; ++kk)
+					if (j0 + 1024u * kk < body)
+						__builtin_memcpy(&v[kk], ps + j0 + 1024u * kk, 16);
 #pragma unroll
-				for (int k = 0; k < 4; ++k)
-					if (j0 + 1024u * k < body)
-						__builtin_memcpy(pd + j0 + 1024u * k, &v[k], 16);
+				for (int kk = 0; kk < 4; ++kk)
+					if (j0 + 1024u * kk < body)
+						__builtin_memcpy(pd + j0 + 1024u * kk, &v[kk], 16);
 			}
 			if (body + lane < L)
 				pd[body + lane] = ps[body + lane];
+			op += L;
+			qh = (qh + 1) & 127u;
+			qn -= 1;
+			continue;
 		}
-		/* ---- pass 3: the other copies, in order (SAW__AppendFromSelf, :295-317) ---- */
-		for (uint64_t dep = ballot64(cpy && !indep); dep; dep &= dep - 1) {
-			const uint32_t t = first_lane(dep);
-			const uint32_t L = rdlane(l, t), OFF = rdlane(off, t);
-			uint8_t *pd = dst + (op + rdlane(excl, t));
-			if (lane < L) {
-				const uint32_t j = lane < OFF ? lane : lane % OFF;
-				pd[lane] = pd[(int32_t)(j - OFF)];
+		if (nfit > 0) {
+			const uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + op) & 15u);
+			const bool mine = lane < nfit;
+			uint8_t *o = ostage + sa + excl;
+			const bool lit = mine && is_lit;
+			const bool cpy = mine && !is_lit;
+			const bool indep = cpy && off >= excl + l; /* source ends in front of this batch's output */
+			/* ---- literals up to 64 bytes (SAW__Append / SAW__AppendFastPath, :264-293) and copies
+			 * that read only what earlier batches produced, one lane per element ---- */
+			copy_exact(o, lit ? src + (at + hsz) : dst + pb - off, l, (lit && l <= 64) || indep, next8);
+			/* ---- longer literals: wave-wide, 16 B per lane ---- */
+			for (uint64_t big = ballot64(lit && l > 64); big; big &= big - 1) {
+				const uint32_t t = first_lane(big);
+				const uint32_t L = rdlane(l, t);
+				const uint8_t *ps = src + (rdlane(at, t) + rdlane(hsz, t));
+				uint8_t *pd = ostage + sa + rdlane(excl, t);
+				const uint32_t body = L & ~15u;
+				for (uint32_t j0 = lane * 16; j0 < body; j0 += 1024) {
+					uint4 v;
+					__builtin_memcpy(&v, ps + j0, 16);
+					__builtin_memcpy(pd + j0, &v, 16);
+				}
+				if (body + lane < L)
+					pd[body + lane] = ps[body + lane];
+			}
+			wave_lds_fence();
+			/* ---- the other copies, in order (SAW__AppendFromSelf, :295-317): source inside this
+			 * batch's output or overlapping itself, dst[j] = dst[j mod offset - offset]; bytes from
+			 * in front of the batch come from HBM, the rest from the staging ---- */
+			for (uint64_t dep = ballot64(cpy && !indep); dep; dep &= dep - 1) {
+				const uint32_t t = first_lane(dep);
+				const uint32_t L = rdlane(l, t), OFF = rdlane(off, t), E = rdlane(excl, t);
+				if (lane < L) {
+					const uint32_t j = lane < OFF ? lane : lane % OFF;
+					const int32_t s = (int32_t)(E + j) - (int32_t)OFF; /* relative to the batch's start */
+					const uint8_t byte = s >= 0 ? ostage[sa + (uint32_t)s] : dst[(int64_t)op + s];
+					ostage[sa + E + lane] = byte;
+				}
+				wave_lds_fence();
+			}
+			/* ---- flush ---- */
+			{
+				const uint32_t total = rdlane(excl, nfit - 1) + rdlane(l, nfit - 1);
+				uint8_t *gbase = dst + op - sa; /* 16 B aligned */
+				const uint32_t end = sa + total;
+				uint32_t first_full = 0;
+				if (sa > 0) {
+					const uint32_t hend = min(16u, end);
+					if (lane >= sa && lane < hend)
+						gbase[lane] = ostage[lane];
+					first_full = 1;
+				}
+				const uint32_t nfull = end >> 4;
+				for (uint32_t cc = first_full + lane; cc < nfull; cc += 64)
+					reinterpret_cast<uint4 *>(gbase)[cc] = reinterpret_cast<const uint4 *>(ostage)[cc];
+				const uint32_t tail0 = nfull << 4;
+				const uint32_t tail = (end > tail0 && (nfull >= 1 || sa == 0)) ? end - tail0 : 0;
+				if (lane < tail)
+					gbase[tail0 + lane] = ostage[tail0 + lane];
+				op += total;
+				wave_lds_fence();
 			}
 		}
-		if (run) {
-			const uint32_t t = 63u - (uint32_t)__builtin_clzll(run); /* last executed element */
-			op += rdlane(excl, t) + rdlane(l, t);
-		}
-		if (fe < 64) {
+		if (fe < 64 && nfit == nrun) {
 			status = (int32_t)rdlane((uint32_t)err, fe);
 			break;
 		}
-		ip = cur >= room ? n : ip + cur;
+		qh = (qh + nfit) & 127u;
+		qn -= nfit;
 	}
 
 	if (lane == 0) {
