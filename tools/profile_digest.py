@@ -58,27 +58,33 @@ try:
 except Exception as e:  # noqa
     summary["bench_line"] = f"unreadable: {e!r}"
 
-# per BATCH CALL figures (what bench.py's HIP events measure).  bench.py calls the compress batch
-# once more than the decompress batch (the bit-exactness check), so every kernel family is divided
-# by ITS OWN number of batch calls = the smallest call count among its members (one launch per
-# chunk and batch; the profiled runs use one chunk).
+# per BATCH CALL figures (what bench.py's HIP events measure).  A compress batch call launches the
+# parser up to three times (two dense table sizes, then the global table; two of them under one
+# kernel name) and the emit kernel once; bench.py calls the compress batch once more than the
+# decompress batch (the bit-exactness check).  So: batch calls of an operation = launches of the
+# kernel that runs exactly once per call (emit / decompress), and every kernel's TOTAL over the
+# run is divided by that.
 try:
-    fam_calls = {}
-    for name, k in summary["kernels"].items():
-        fam_calls[family(name)] = min(fam_calls.get(family(name), 1 << 60), k["calls"])
+    def batches_of(fam, counts):
+        once = "snappy_emit_blocks" if fam in ("snappy_parse_fragments", "snappy_emit_blocks") else fam
+        return max(counts.get(once, 0), 1)
+    calls = {n: k["calls"] for n, k in summary["kernels"].items()}
     for name, k in summary["kernels"].items():
         f = summary["per_batch"].setdefault(family(name), {"ms": 0.0, "launches_per_batch": 0.0})
-        f["ms"] += k["total_ns"] / fam_calls[family(name)] / 1e6
-        f["launches_per_batch"] += k["calls"] / fam_calls[family(name)]
-    for name, v in summary["pmc"].items():
-        f = summary["per_batch"].setdefault(family(name), {})
-        if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
-            # one launch of each member kernel per batch call
-            fetch = v["FETCH_SIZE_KiB_per_launch"] * 1024
-            write = v["WRITE_SIZE_KiB_per_launch"] * 1024
-            f["fetch_bytes_raw"] = f.get("fetch_bytes_raw", 0) + int(fetch)
-            f["write_bytes_raw"] = f.get("write_bytes_raw", 0) + int(write)
-            f["hbm_bytes_corrected"] = f.get("hbm_bytes_corrected", 0) + int(2 * fetch + write)
+        b = batches_of(family(name), calls)
+        f["ms"] += k["total_ns"] / b / 1e6
+        f["launches_per_batch"] += k["calls"] / b
+    for counter, key in (("FETCH_SIZE", "fetch_bytes_raw"), ("WRITE_SIZE", "write_bytes_raw")):
+        counts = {n: v.get("launches_" + counter, 0) for n, v in summary["pmc"].items()}
+        for name, v in summary["pmc"].items():
+            if counter + "_KiB_per_launch" not in v:
+                continue
+            f = summary["per_batch"].setdefault(family(name), {})
+            total = v[counter + "_KiB_per_launch"] * v["launches_" + counter] * 1024
+            f[key] = f.get(key, 0) + int(total / batches_of(family(name), counts))
+    for f in summary["per_batch"].values():
+        if "fetch_bytes_raw" in f and "write_bytes_raw" in f:
+            f["hbm_bytes_corrected"] = 2 * f["fetch_bytes_raw"] + f["write_bytes_raw"]
 except Exception as e:  # noqa
     summary["per_batch"] = f"unavailable: {e!r}"
 print(json.dumps(summary, indent=1))
