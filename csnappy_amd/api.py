@@ -28,7 +28,8 @@ HIP_SYMBOLS = [
     "csnappy_hip_device_count", "csnappy_hip_last_error", "csnappy_hip_compress_workspace_size",
     "csnappy_hip_compress_batch", "csnappy_hip_decompress_batch", "csnappy_hip_set_kernel_timing",
     "csnappy_hip_get_kernel_timing", "csnappy_hip_workload_generate", "csnappy_hip_compact_batch",
-    "csnappy_workload_generate_host",
+    "csnappy_workload_generate_host", "csnappy_hip_decompress_stream_workspace_size",
+    "csnappy_hip_decompress_stream", "csnappy_hip_decompress_stream_took_fast_path",
 ]
 
 FRAME_SYMBOLS = [
@@ -80,6 +81,12 @@ def lib():
                                              C.c_size_t, vp]
     L.csnappy_hip_decompress_batch.restype = i32
     L.csnappy_hip_decompress_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, i32, vp]
+    L.csnappy_hip_decompress_stream_workspace_size.restype = C.c_size_t
+    L.csnappy_hip_decompress_stream_workspace_size.argtypes = [u32, u32]
+    L.csnappy_hip_decompress_stream.restype = i32
+    L.csnappy_hip_decompress_stream.argtypes = [vp, u32, u32, vp, vp, vp, vp, C.c_size_t, vp]
+    L.csnappy_hip_decompress_stream_took_fast_path.restype = i32
+    L.csnappy_hip_decompress_stream_took_fast_path.argtypes = [vp, u32, u32, vp]
     L.csnappy_hip_compact_batch.restype = i32
     L.csnappy_hip_compact_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.csnappy_hip_set_kernel_timing.restype = None
@@ -237,6 +244,24 @@ def decompress_batch(d_in, in_off, in_len, d_out, out_off, out_cap, status, prod
         out_off.data_ptr(), out_cap.data_ptr(), status.data_ptr(), produced.data_ptr(), mode,
         _stream())
     _check(rc, "csnappy_hip_decompress_batch")
+
+
+def decompress_stream(d_body, ulength, d_out):
+    """One stream body (no length header) of any length, device to device: -> (status, produced,
+    took_fast_path).  d_out must hold ulength bytes."""
+    import torch
+    n = d_body.numel()
+    need = lib().csnappy_hip_decompress_stream_workspace_size(n, ulength)
+    ws = torch.empty(need + 16, dtype=torch.uint8, device=d_body.device)
+    ws = ws[(-ws.data_ptr()) % 16:]
+    res = torch.zeros(2, dtype=torch.int32, device=d_body.device)
+    rc = lib().csnappy_hip_decompress_stream(d_body.data_ptr(), n, ulength, d_out.data_ptr(),
+                                             res.data_ptr(), res.data_ptr() + 4, ws.data_ptr(),
+                                             need, _stream())
+    _check(rc, "csnappy_hip_decompress_stream")
+    fast = lib().csnappy_hip_decompress_stream_took_fast_path(ws.data_ptr(), n, ulength, _stream())
+    status, produced = res.cpu().tolist()
+    return status, produced & 0xFFFFFFFF, bool(fast)
 
 
 def compact_batch(d_out, out_off, out_len, dense_off, dense):

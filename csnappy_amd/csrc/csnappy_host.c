@@ -216,6 +216,44 @@ out:
 	return status;
 }
 
+/* csnappy_decompress of a long stream: the body goes to csnappy_hip_decompress_stream, which
+ * spreads it over the device when its fragments can be told apart (include/csnappy_hip.h) */
+#define STREAM_CALL_MIN_BODY (128u * 1024u)
+
+static int decompress_stream_on_device(const char *body, uint32_t body_len, char *dst, uint32_t olen)
+{
+	struct desc d;
+	size_t ws_need;
+	int status = CSNAPPY_E_HIP_UNAVAILABLE;
+	char *dd;
+
+	pthread_mutex_lock(&g.mu);
+	if (ctx_init() < 0)
+		goto out;
+	ws_need = csnappy_hip_decompress_stream_workspace_size(body_len, olen);
+	if (grow(&g.in, (size_t)body_len + 64) || grow(&g.out, (size_t)olen + 64) ||
+	    grow(&g.ws, ws_need) || grow(&g.desc, sizeof(d)))
+		goto out;
+	dd = (char *)g.desc.p;
+	if (hipMemcpyAsync(g.in.p, body, body_len, hipMemcpyHostToDevice, g.stream) != hipSuccess)
+		goto out;
+	if (csnappy_hip_decompress_stream(g.in.p, body_len, olen, g.out.p,
+					  (int32_t *)(dd + offsetof(struct desc, status)),
+					  (uint32_t *)(dd + offsetof(struct desc, produced)), g.ws.p,
+					  g.ws.cap, g.stream))
+		goto out;
+	if (hipMemcpyAsync(&d, g.desc.p, sizeof(d), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+	    hipStreamSynchronize(g.stream) != hipSuccess)
+		goto out;
+	if (d.status == CSNAPPY_E_OK && d.produced &&
+	    hipMemcpy(dst, g.out.p, d.produced, hipMemcpyDeviceToHost) != hipSuccess)
+		goto out;
+	status = d.status;
+out:
+	pthread_mutex_unlock(&g.mu);
+	return status;
+}
+
 /* Most bytes a Snappy body of n bytes can expand to: a 3-byte copy tag yields up to 64 bytes. */
 static uint32_t expansion_bound(uint32_t n)
 {
@@ -226,12 +264,16 @@ static uint32_t expansion_bound(uint32_t n)
 int csnappy_decompress(const char *src, uint32_t src_len, char *dst, uint32_t dst_len)
 {
 	uint32_t produced = 0, olen = 0, alloc;
+	int hdr;
 	/* header errors are decided on the host, as in the reference, before anything is allocated:
 	 * -1 for an unparsable length, -2 when dst is too small (csnappy_decompress.c:399-409) */
-	if (csnappy_get_uncompressed_length(src, src_len, &olen) < 0)
+	hdr = csnappy_get_uncompressed_length(src, src_len, &olen);
+	if (hdr < 0)
 		return CSNAPPY_E_HEADER_BAD;
 	if (olen > dst_len)
 		return CSNAPPY_E_OUTPUT_INSUF;
+	if (src_len - (uint32_t)hdr >= STREAM_CALL_MIN_BODY && olen < 0xffff0000u && src_len < 0xffff0000u)
+		return decompress_stream_on_device(src + hdr, src_len - (uint32_t)hdr, dst, olen);
 	/* the kernel never writes past the header length, nor can the body expand past its bound */
 	alloc = olen < expansion_bound(src_len) ? olen : expansion_bound(src_len);
 	return decompress_on_device(src, src_len, dst, dst_len, alloc, &produced, CSNAPPY_HIP_STREAM);

@@ -89,6 +89,7 @@ struct DecompressArgs {
 	uint32_t *produced;
 	uint32_t nblocks;
 	int mode;
+	const uint32_t *skip_if; /* not null and *skip_if != 0: nothing to do (the stream fast path's result stands) */
 };
 
 DEVINL uint32_t rdlane(uint32_t v, uint32_t l)
@@ -1470,6 +1471,22 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, 
 
 constexpr uint32_t kOutStage = 2048; /* bytes of a batch's output assembled in LDS */
 
+/* The reference's char_table (csnappy_decompress.c:152-185) as the kernels use it, computed by
+ * the wave (4 entries per lane): bits 0-6 length (0 for a literal whose length follows in extra
+ * bytes), 7-9 extra bytes after the tag, 10-12 offset bits 8..10 of a 1-byte-offset copy, 13 literal */
+DEVINL void fill_tag_table(uint16_t *ctab, uint32_t lane)
+{
+	for (uint32_t b = lane; b < 256; b += 64) {
+		const uint32_t kd = b & 3, up = b >> 2;
+		const uint32_t lx = max(up, 59u) - 59u;          /* literal: extra length bytes 0..4, :351-353 */
+		const uint32_t cx = kd + ((kd >> 1) & kd);        /* copy: offset bytes 1, 2, 4 */
+		const uint32_t len = kd == 1 ? 4 + (up & 7) : up + 1;
+		ctab[b] = (uint16_t)((kd == 0 && lx ? 0 : len) | ((kd == 0 ? lx : cx) << 7) |
+				     ((kd == 1 ? b >> 5 : 0u) << 10) | ((kd == 0 ? 1u : 0u) << 13));
+	}
+	wave_lds_fence();
+}
+
 extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(DecompressArgs A)
 {
 	/* 32-bit cursors: in_len and out_cap are uint32 in the reference API too; the batch API asks
@@ -1482,15 +1499,9 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	const uint32_t cap = A.out_cap[blk];
 	/* the tag table, computed once per wave (4 entries per lane) */
 	__shared__ uint16_t ctab[256];
-	for (uint32_t b = lane; b < 256; b += 64) {
-		const uint32_t kd = b & 3, up = b >> 2;
-		const uint32_t lx = max(up, 59u) - 59u;          /* literal: extra length bytes 0..4, :351-353 */
-		const uint32_t cx = kd + ((kd >> 1) & kd);        /* copy: offset bytes 1, 2, 4 */
-		const uint32_t len = kd == 1 ? 4 + (up & 7) : up + 1;
-		ctab[b] = (uint16_t)((kd == 0 && lx ? 0 : len) | ((kd == 0 ? lx : cx) << 7) |
-				     ((kd == 1 ? b >> 5 : 0u) << 10) | ((kd == 0 ? 1u : 0u) << 13));
-	}
-	wave_lds_fence();
+	if (A.skip_if && *A.skip_if)
+		return;
+	fill_tag_table(ctab, lane);
 
 	uint32_t ip = 0;
 	uint32_t limit = cap;
@@ -1572,10 +1583,21 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			const uint32_t room = n - ip; /* > 0 */
 			const uint32_t wlim = min(64u, room);
 			const uint32_t nxt = lane + esz < lane ? 0xffffffffu : lane + esz; /* next tag if I am one */
+			/* The walk: two instructions per tag (s_bitset1 + v_readlane) in groups of four.  A step
+			 * that leaves the window goes back to lane 0, where the walk only marks tags again that
+			 * are marked already, so the end is tested once per group: the steps taken no longer
+			 * equal the tags marked.  (The scalar unit is the busiest one in this kernel.) */
+			const uint32_t nxw = nxt < wlim ? nxt : 0u;
+			uint32_t steps = 0;
 			do {
-				tmask |= 1ull << cur;
-				cur = rdlane(nxt, cur);
-			} while (cur < wlim);
+#pragma unroll
+				for (int kk = 0; kk < 4; ++kk) {
+					asm("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(cur));
+					cur = rdlane(nxw, cur);
+				}
+				steps += 4;
+			} while ((uint32_t)__builtin_popcountll(tmask) == steps);
+			cur = rdlane(nxt, 63u - (uint32_t)__builtin_clzll(tmask)); /* where the last tag's element ends */
 			/* request the next iteration's bytes now */
 			have_next = cur < room && room - cur >= 64 + 8;
 			if (have_next)
@@ -1666,8 +1688,9 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			 * that read only what earlier batches produced, one lane per element ---- */
 			copy_exact(o, lit ? src + (at + hsz) : dst + pb - off, l, (lit && l <= 64) || indep, next8);
 			/* ---- longer literals: wave-wide, 16 B per lane ---- */
-			for (uint64_t big = ballot64(lit && l > 64); big; big &= big - 1) {
+			for (uint64_t big = ballot64(lit && l > 64); big;) {
 				const uint32_t t = first_lane(big);
+				asm("s_bitset0_b64 %0, %1" : "+s"(big) : "s"(t));
 				const uint32_t L = rdlane(l, t);
 				const uint8_t *ps = src + (rdlane(at, t) + rdlane(hsz, t));
 				uint8_t *pd = ostage + sa + rdlane(excl, t);
@@ -1684,14 +1707,18 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			/* ---- the other copies, in order (SAW__AppendFromSelf, :295-317): source inside this
 			 * batch's output or overlapping itself, dst[j] = dst[j mod offset - offset]; bytes from
 			 * in front of the batch come from HBM, the rest from the staging ---- */
-			for (uint64_t dep = ballot64(cpy && !indep); dep; dep &= dep - 1) {
+			for (uint64_t dep = ballot64(cpy && !indep); dep;) {
 				const uint32_t t = first_lane(dep);
+				asm("s_bitset0_b64 %0, %1" : "+s"(dep) : "s"(t));
 				const uint32_t L = rdlane(l, t), OFF = rdlane(off, t), E = rdlane(excl, t);
 				if (lane < L) {
 					const uint32_t j = lane < OFF ? lane : lane % OFF;
 					const int32_t s = (int32_t)(E + j) - (int32_t)OFF; /* relative to the batch's start */
-					const uint8_t byte = s >= 0 ? ostage[sa + (uint32_t)s] : dst[(int64_t)op + s];
-					ostage[sa + E + lane] = byte;
+					uint32_t byte = ostage[sa + (uint32_t)max(s, 0)];
+					asm volatile("" : "+v"(byte)); /* keeps the two loads apart (merged, they become one flat load) */
+					if (s < 0)
+						byte = dst[(int64_t)op + s];
+					ostage[sa + E + lane] = (uint8_t)byte;
 				}
 				wave_lds_fence();
 			}
@@ -1729,6 +1756,506 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	if (lane == 0) {
 		A.status[blk] = status;
 		A.produced[blk] = status == CSNAPPY_E_OK ? op : 0;
+	}
+}
+
+/* ==========================================================================================
+ * STREAM INDEX: one long stream decoded by many waves  
+ *
+ * csnappy_decompress (csnappy_decompress.c:390-415) walks a stream of any length tag by tag; the
+ * batch kernel above does the same with one wave per stream, which is correct for every stream
+ * but leaves a 5 MiB file to a single wave.  What makes a stream divisible is the compressor's
+ * fragmenting (csnappy_compress.c:585-616): csnappy_compress restarts its table every 32 KiB of
+ * input, so no copy reaches across a multiple of 32 KiB of OUTPUT and an element starts at each of
+ * them.  The pre-pass below finds those elements without decoding anything:
+ *   index    one wave per 4 KiB segment of the compressed bytes parses it speculatively from its
+ *            first byte (which is usually not a tag): per 64-byte window the tags it met and the
+ *            bytes they produce.  Parses that start at different bytes fall into step after a few
+ *            elements, and from a common tag on they are the same parse.
+ *   chain    one wave strings the segments together.  An element that reaches beyond its segment
+ *            (a long literal) is followed exactly, its successor's header is read on the spot.
+ *            Otherwise the parse leaves segment k where settle saw it leave when entered at this
+ *            very byte, and failing that where the speculative parse left it -- an assumption.
+ *   settle   one wave per segment walks the parse from its entry until it meets the speculative
+ *            one, corrects the windows in front of that point and notes "entered here, leaves
+ *            there" (with the speculative parse if they met, else on its own: literal bytes parse
+ *            to anything).  If chain had assumed otherwise, both run again: up to kStreamRounds
+ *            rounds, skipped once nothing changes.  A round gets at least one more segment right,
+ *            and at the fixed point every entry is the true one, by induction from the first.
+ *            Segments a round's parse does not touch are walked from where their neighbour in
+ *            front leaves, so that most exits are known before the parse comes through.
+ *   scan     exclusive sum of the segments' output bytes.
+ *   bounds   one wave per segment looks for elements that start at a multiple of 32 KiB of output.
+ *   describe one thread per fragment turns the boundaries into batch descriptors.
+ * Then snappy_decompress_blocks decodes the fragments as independent no-header blocks, a verdict
+ * kernel accepts the result only if every fragment decoded cleanly to exactly its size, the
+ * parse ended at the last input byte and the sizes add up to the expected length -- in that case
+ * the one-wave decode would have executed the same elements on the same bytes.  In every other
+ * case (a foreign compressor that copies across 32 KiB, a damaged stream, an element larger than
+ * a fragment) the one-wave decode runs and its result, error code included, is the answer.
+ * ======================================================================================== */
+constexpr uint32_t kSegBytes = 4096;       /* 64 windows of 64 bytes: one window per lane */
+constexpr uint32_t kNoEntry = 0xffffffffu; /* the true parse does not touch this segment */
+constexpr uint32_t kHugeOut = 1u << 24;    /* window outputs saturate here; no fragment holds that much */
+
+struct StreamArgs {
+	const uint8_t *in;   /* the body: the stream without its length header */
+	uint32_t n, ulength; /* its bytes; the bytes it is expected to produce */
+	uint32_t nseg, nfrag;
+	uint64_t *tagmask;   /* [nseg * 64] tags met in each window */
+	uint32_t *winout;    /* [nseg * 64] bytes they produce (saturating) */
+	uint64_t *truemask;  /* [nseg * 64] the same of the true parse (settle) */
+	uint32_t *trueout;
+	/* per segment [nseg]: */
+	uint32_t *seg_exit;  /* where the speculative parse left it ... */
+	uint32_t *seg_xesz;  /* ... and the input bytes of the element that starts there */
+	uint32_t *seg_entry; /* where this round's parse enters it, or kNoEntry */
+	uint32_t *seg_used;  /* where chain took this round's parse to leave it */
+	uint32_t *seg_guess; /* where the parse would enter coming out of the segment in front, or kNoEntry */
+	/* what settle found: "entered at .entry, the parse leaves at .leave, where an element of .lesz
+	 * input bytes starts" -- [0..nseg) for an entry on a round's parse, [nseg..2 nseg) for a guess */
+	uint32_t *memo_entry, *memo_leave, *memo_lesz;
+	uint64_t *seg_out;   /* [nseg] bytes the segment produces; after the scan, its output offset */
+	uint32_t *frag_pos;  /* [nfrag] input position of the element that starts fragment f */
+	uint64_t *f_in_off, *f_out_off; /* [nfrag] batch descriptors of the fragments ... */
+	uint32_t *f_in_len, *f_out_cap, *f_produced;
+	int32_t *f_status;
+	uint64_t *one_off;   /* ... and [2] zeros: offsets of the one-block slow path */
+	uint32_t *one_len;   /* [2] n, ulength: its in_len and out_cap */
+	uint32_t *flags;     /* SF_*: refused, end of the true parse, verdict (1 = fragments stand), round state */
+	uint32_t round;
+	uint64_t *total;     /* [1] bytes the parse produces */
+	int32_t *status;     /* the caller's result */
+	uint32_t *produced;
+};
+/* SF_CHANGED / SF_RESUME have one slot per round parity: settle of round r writes slot r & 1, chain
+ * of round r + 1 reads it and resets the other one.  (Reading and resetting the same word in one
+ * kernel is not safe: the compiler reads such a word through the scalar cache, and that load is
+ * not ordered against the vector store behind it.) */
+enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_ACTIVE = 3, SF_ROUNDS = 4, SF_CHANGED = 6, SF_RESUME = 8, SF_COUNT = 12 };
+constexpr uint32_t kStreamRounds = 16;
+
+struct TagAt {
+	uint32_t esz; /* bytes the element takes in the input (saturating) */
+	uint32_t l;   /* bytes it produces (saturating at kHugeOut) */
+};
+
+/* the byte at `at` read as a tag (csnappy_decompress.c:348-365 as selects; the same arithmetic as
+ * the decompressor's scan).  Header bytes beyond the input read as 0: such an element ends beyond
+ * the input whatever they were, which is all that matters here. */
+DEVINL TagAt tag_at(const uint8_t *src, uint32_t n, uint32_t at, const uint16_t *ctab)
+{
+	uint32_t b0 = 0, tr = 0;
+	if (at + 8 <= n) {
+		uint64_t v;
+		__builtin_memcpy(&v, src + at, 8);
+		b0 = (uint32_t)v & 0xff;
+		tr = (uint32_t)(v >> 8);
+	} else {
+		if (at < n)
+			b0 = src[at];
+#pragma unroll
+		for (int kk = 0; kk < 4; ++kk)
+			if (at + 1 + kk < n)
+				tr |= (uint32_t)src[at + 1 + kk] << (8 * kk);
+	}
+	const uint32_t e = ctab[b0];
+	const uint32_t extra = (e >> 7) & 7u;
+	const bool is_lit = (e >> 13) & 1u;
+	const uint32_t trm = tr & (0xffffffffu >> ((32u - 8u * extra) & 31u));
+	const uint32_t l = (is_lit && extra != 0) ? trm + 1 : (e & 127u);
+	const uint32_t hsz = 1 + extra;
+	TagAt t;
+	t.esz = is_lit ? (l >= 0xfffffff0u ? 0xfffffff8u : hsz + l) : hsz;
+	t.l = min(l, kHugeOut);
+	return t;
+}
+
+DEVINL uint64_t rdlane64(uint64_t v, uint32_t l)
+{
+	return (uint64_t)rdlane((uint32_t)v, l) | ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32);
+}
+
+/* The tags of one window on the parse that enters it at lane `start` (< wlim = bytes of the window
+ * inside the input): each tag names the next one, nxt = lane + bytes its element takes.  Same walk
+ * as the decompressor's: a step out of the window goes back to `start`, where nothing new is
+ * marked.  *leave = window-relative position at which the parse leaves (>= wlim). */
+DEVINL uint64_t walk_window(uint32_t esz, uint32_t lane, uint32_t start, uint32_t wlim, uint64_t *leave)
+{
+	const uint32_t nxt = lane + esz < lane ? 0xffffffffu : lane + esz;
+	const uint32_t nxw = nxt < wlim ? nxt : start;
+	uint64_t tmask = 0;
+	uint32_t cur = start, steps = 0;
+	do {
+#pragma unroll
+		for (int kk = 0; kk < 4; ++kk) {
+			asm("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(cur));
+			cur = rdlane(nxw, cur);
+		}
+		steps += 4;
+	} while ((uint32_t)__builtin_popcountll(tmask) == steps);
+	*leave = rdlane(nxt, 63u - (uint32_t)__builtin_clzll(tmask));
+	return tmask;
+}
+
+/* bytes the tags in `mask` produce, saturating */
+DEVINL uint32_t window_out(uint64_t mask, uint32_t l, uint32_t lane)
+{
+	const uint32_t x = wave_incl_scan_dpp(((mask >> lane) & 1) ? l : 0u);
+	return min(rdlane(x, 63), kHugeOut);
+}
+
+extern "C" __global__ void __launch_bounds__(64) snappy_stream_index(StreamArgs A)
+{
+	__shared__ uint16_t ctab[256];
+	const uint32_t lane = threadIdx.x, seg = blockIdx.x;
+	fill_tag_table(ctab, lane);
+	const uint32_t seg_lo = seg * kSegBytes;
+	uint64_t pos = seg_lo; /* next tag of the speculative parse */
+	uint64_t my_mask = 0;
+	uint32_t my_out = 0;
+	TagAt t = tag_at(A.in, A.n, seg_lo + lane, ctab);
+	for (uint32_t w = 0; w < 64; ++w) {
+		const uint32_t base = seg_lo + 64 * w;
+		if (base >= A.n)
+			break;
+		const TagAt cur = t;
+		if (w + 1 < 64 && base + 64 < A.n)
+			t = tag_at(A.in, A.n, base + 64 + lane, ctab); /* in flight during the walk */
+		const uint32_t wlim = min(64u, A.n - base);
+		if (pos >= (uint64_t)base + wlim)
+			continue;
+		uint64_t leave;
+		const uint64_t mask = walk_window(cur.esz, lane, (uint32_t)(pos - base), wlim, &leave);
+		const uint32_t out = window_out(mask, cur.l, lane);
+		pos = base + leave;
+		if (lane == w) {
+			my_mask = mask;
+			my_out = out;
+		}
+	}
+	A.tagmask[(size_t)seg * 64 + lane] = my_mask;
+	A.winout[(size_t)seg * 64 + lane] = my_out;
+	const uint32_t leave = pos > 0xffffffffull ? 0xffffffffu : (uint32_t)pos;
+	const TagAt next = tag_at(A.in, A.n, leave, ctab); /* (every lane the same tag) */
+	if (lane == 0) {
+		A.seg_exit[seg] = leave;
+		A.seg_xesz[seg] = next.esz;
+		A.memo_entry[seg] = kNoEntry;
+		A.memo_entry[A.nseg + seg] = kNoEntry;
+	}
+}
+
+/* what is known about the segments of one 64-segment chunk, one per lane */
+struct ChainChunk {
+	uint32_t sx, sz;     /* speculative exit */
+	uint32_t te, tl, tz; /* settle's note for an entry on a round's parse */
+	uint32_t ge, gl, gz; /* ... and for a guessed entry */
+};
+
+DEVINL ChainChunk chain_load(const StreamArgs &A, uint32_t c, uint32_t lane)
+{
+	const uint32_t k = c + lane < A.nseg ? c + lane : 0u;
+	ChainChunk C;
+	C.sx = A.seg_exit[k];
+	C.sz = A.seg_xesz[k];
+	C.te = A.memo_entry[k];
+	C.tl = A.memo_leave[k];
+	C.tz = A.memo_lesz[k];
+	C.ge = A.memo_entry[A.nseg + k];
+	C.gl = A.memo_leave[A.nseg + k];
+	C.gz = A.memo_lesz[A.nseg + k];
+	return C;
+}
+
+/* where the parse leaves a segment as far as anyone knows */
+DEVINL uint32_t chain_best(const ChainChunk &C)
+{
+	return C.te != kNoEntry ? C.tl : C.ge != kNoEntry ? C.gl : C.sx;
+}
+
+extern "C" __global__ void __launch_bounds__(64) snappy_stream_chain(StreamArgs A)
+{
+	__shared__ uint16_t ctab[256];
+	const uint32_t lane = threadIdx.x;
+	/* rounds after the first run only while the previous settle changed something, and pick the
+	 * parse up at the first segment it changed (everything in front has been confirmed) */
+	const uint32_t mine = A.round & 1, last = mine ^ 1;
+	const bool active = A.round == 0 || A.flags[SF_CHANGED + last] != 0;
+	const uint32_t first = A.round == 0 ? 0u : A.flags[SF_RESUME + last];
+	if (lane == 0) {
+		A.flags[SF_ACTIVE] = active ? 1u : 0u;
+		A.flags[SF_CHANGED + mine] = 0;
+		A.flags[SF_RESUME + mine] = 0xffffffffu;
+		if (active)
+			A.flags[SF_ROUNDS] = A.round + 1;
+	}
+	if (!active || first >= A.nseg)
+		return;
+	fill_tag_table(ctab, lane);
+	uint32_t e = first == 0 ? 0u : A.seg_entry[first]; /* the parse is here ... */
+	uint32_t esz = rdlane(tag_at(A.in, A.n, e, ctab).esz, 0); /* ... at an element of this many bytes */
+	const uint32_t c0 = first & ~63u;
+	uint32_t front_leaves = 0;
+	if (c0 > 0)
+		front_leaves = rdlane(chain_best(chain_load(A, c0 - 1, lane)), 0);
+	ChainChunk N = chain_load(A, c0, lane);
+	for (uint32_t c = c0; c < A.nseg; c += 64) {
+		const ChainChunk C = N;
+		if (c + 64 < A.nseg)
+			N = chain_load(A, c + 64, lane); /* in flight while this chunk is walked */
+		const bool have = c + lane < A.nseg;
+		const uint32_t k = c + lane;
+		/* Segments this round's parse will not touch are walked by settle all the same, from
+		 * where the segment in front leaves as far as anyone knows: most exits are then known
+		 * by the time the parse does come through. */
+		{
+			const uint32_t best = chain_best(C);
+			const uint32_t up = (uint32_t)__shfl_up((int)best, 1);
+			const uint32_t from = lane == 0 ? front_leaves : up;
+			const uint64_t lo64 = (uint64_t)k * kSegBytes;
+			const uint64_t hi64 = lo64 + kSegBytes < A.n ? lo64 + kSegBytes : A.n;
+			if (have)
+				A.seg_guess[k] = (k > 0 && from >= lo64 && from < hi64) ? from : kNoEntry;
+			front_leaves = rdlane(best, 63);
+		}
+		uint32_t ent = kNoEntry, used = 0;
+		const uint32_t m = min(64u, A.nseg - c);
+		for (uint32_t j = c == c0 ? first - c0 : 0u; j < m; ++j) {
+			const uint64_t hi64 = (uint64_t)(c + j + 1) * kSegBytes;
+			const uint32_t hi = hi64 < A.n ? (uint32_t)hi64 : A.n;
+			if (e >= hi)
+				continue; /* inside an element that started earlier */
+			if (lane == j)
+				ent = e;
+			const uint64_t after = (uint64_t)e + esz;
+			if (after >= hi) {
+				/* the element at the entry reaches beyond the segment: follow it */
+				e = after > 0xffffffffull ? 0xffffffffu : (uint32_t)after;
+				esz = rdlane(tag_at(A.in, A.n, e, ctab).esz, 0);
+			} else if (e == rdlane(C.te, j)) {
+				e = rdlane(C.tl, j);
+				esz = rdlane(C.tz, j);
+			} else if (e == rdlane(C.ge, j)) {
+				e = rdlane(C.gl, j);
+				esz = rdlane(C.gz, j);
+			} else {
+				e = rdlane(C.sx, j);
+				esz = rdlane(C.sz, j);
+			}
+			if (lane == j)
+				used = e;
+		}
+		if (have && k >= first) {
+			A.seg_entry[k] = ent;
+			A.seg_used[k] = used;
+		}
+	}
+	if (lane == 0)
+		A.flags[SF_END] = e;
+}
+
+extern "C" __global__ void __launch_bounds__(64) snappy_stream_settle(StreamArgs A)
+{
+	__shared__ uint16_t ctab[256];
+	const uint32_t lane = threadIdx.x, seg = blockIdx.x;
+	if (!A.flags[SF_ACTIVE])
+		return;
+	uint32_t entry = A.seg_entry[seg];
+	const bool flown_over = entry == kNoEntry;
+	if (flown_over) {
+		entry = A.seg_guess[seg];
+		if (entry == A.memo_entry[A.nseg + seg])
+			entry = kNoEntry; /* walked from there before */
+	}
+	uint64_t my_mask = A.tagmask[(size_t)seg * 64 + lane];
+	uint32_t my_out = A.winout[(size_t)seg * 64 + lane];
+	if (entry == kNoEntry) {
+		my_mask = 0;
+		my_out = 0;
+	} else {
+		fill_tag_table(ctab, lane);
+		const uint32_t seg_lo = seg * kSegBytes;
+		const uint32_t w0 = (entry - seg_lo) >> 6;
+		if (lane < w0) {
+			my_mask = 0;
+			my_out = 0;
+		}
+		uint64_t pos = entry;
+		bool met = false;
+		for (uint32_t w = w0; w < 64 && !met; ++w) {
+			const uint32_t base = seg_lo + 64 * w;
+			if (base >= A.n)
+				break;
+			const uint32_t wlim = min(64u, A.n - base);
+			uint64_t fin = 0;
+			uint32_t out = 0;
+			if (pos < (uint64_t)base + wlim) {
+				const TagAt t = tag_at(A.in, A.n, base + lane, ctab);
+				uint64_t leave;
+				const uint64_t mine = walk_window(t.esz, lane, (uint32_t)(pos - base), wlim, &leave);
+				const uint64_t spec = rdlane64(my_mask, w);
+				const uint64_t both = mine & spec;
+				fin = mine;
+				if (both) {
+					/* from their first common tag on, the two parses are one */
+					const uint64_t below = (1ull << first_lane(both)) - 1;
+					fin = (mine & below) | (spec & ~below);
+					met = true;
+				}
+				out = window_out(fin, t.l, lane);
+				pos = base + leave;
+			}
+			if (lane == w) {
+				my_mask = fin;
+				my_out = out;
+			}
+		}
+		/* where the parse leaves: with the speculative one if they met, else on its own */
+		const uint32_t leave = met ? A.seg_exit[seg] : pos > 0xffffffffull ? 0xffffffffu : (uint32_t)pos;
+		const uint32_t lesz = met ? A.seg_xesz[seg] : tag_at(A.in, A.n, leave, ctab).esz;
+		if (lane == 0) {
+			const uint32_t slot = flown_over ? A.nseg + seg : seg;
+			A.memo_entry[slot] = entry;
+			A.memo_leave[slot] = leave;
+			A.memo_lesz[slot] = lesz;
+			if (!flown_over && leave != A.seg_used[seg]) {
+				A.flags[SF_CHANGED + (A.round & 1)] = 1; /* the segments behind may be entered elsewhere */
+				atomicMin(&A.flags[SF_RESUME + (A.round & 1)], seg);
+			}
+		}
+	}
+	if (flown_over) {
+		my_mask = 0;
+		my_out = 0;
+	}
+	A.truemask[(size_t)seg * 64 + lane] = my_mask;
+	A.trueout[(size_t)seg * 64 + lane] = my_out;
+	const uint32_t incl = wave_incl_scan_dpp(min(my_out, kHugeOut));
+	if (lane == 63)
+		A.seg_out[seg] = incl;
+}
+
+/* exclusive sum of seg_out in place: one workgroup, each thread a contiguous run */
+extern "C" __global__ void __launch_bounds__(1024) snappy_stream_scan(StreamArgs A)
+{
+	__shared__ uint64_t part[1024];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t run = (A.nseg + 1023) / 1024;
+	const uint32_t lo = min(tid * run, A.nseg), hi = min(lo + run, A.nseg);
+	uint64_t s = 0;
+	for (uint32_t k = lo; k < hi; ++k)
+		s += A.seg_out[k];
+	part[tid] = s;
+	__syncthreads();
+	if (tid == 0) {
+		uint64_t acc = 0;
+		for (uint32_t k = 0; k < 1024; ++k) {
+			const uint64_t v = part[k];
+			part[k] = acc;
+			acc += v;
+		}
+		A.total[0] = acc;
+	}
+	__syncthreads();
+	uint64_t acc = part[tid];
+	for (uint32_t k = lo; k < hi; ++k) {
+		const uint64_t v = A.seg_out[k];
+		A.seg_out[k] = acc;
+		acc += v;
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(64) snappy_stream_bounds(StreamArgs A)
+{
+	__shared__ uint16_t ctab[256];
+	const uint32_t lane = threadIdx.x, seg = blockIdx.x;
+	const uint64_t my_mask = A.truemask[(size_t)seg * 64 + lane];
+	const uint32_t my_out = min(A.trueout[(size_t)seg * 64 + lane], kHugeOut);
+	const uint64_t O = A.seg_out[seg];
+	/* an element of 16 MiB is no part of a 32 KiB fragment (and the sums stayed inside 32 bits) */
+	if (ballot64(my_out >= kHugeOut) && lane == 0)
+		atomicOr(&A.flags[SF_REFUSED], 2u);
+	const uint32_t incl = wave_incl_scan_dpp(my_out);
+	const uint32_t seg_out = rdlane(incl, 63);
+	const uint32_t my_start = incl - my_out; /* output offset of my window inside the segment */
+	uint64_t M = (O + (kFragment - 1)) & ~(uint64_t)(kFragment - 1);
+	if (M >= O + seg_out)
+		return;
+	fill_tag_table(ctab, lane);
+	for (; M < O + seg_out; M += kFragment) {
+		const uint32_t rel = (uint32_t)(M - O);
+		const uint64_t holds = ballot64(my_start <= rel && rel - my_start < my_out);
+		if (!holds)
+			continue; /* cannot happen: the windows tile the segment's output */
+		const uint32_t w = first_lane(holds);
+		const uint32_t base = seg * kSegBytes + 64 * w;
+		const uint64_t mask = rdlane64(my_mask, w);
+		const TagAt t = tag_at(A.in, A.n, base + lane, ctab);
+		const bool tag = (mask >> lane) & 1;
+		const uint32_t mine = tag ? t.l : 0u;
+		const uint32_t pre = wave_incl_scan_dpp(mine) - mine;
+		const uint64_t hit = ballot64(tag && rdlane(my_start, w) + pre == rel);
+		if (hit && lane == 0 && (M >> 15) < A.nfrag)
+			A.frag_pos[M >> 15] = base + first_lane(hit);
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(256) snappy_stream_describe(StreamArgs A)
+{
+	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+	if (f >= A.nfrag)
+		return;
+	const uint32_t pos = A.frag_pos[f];
+	const uint32_t end = f + 1 < A.nfrag ? A.frag_pos[f + 1] : A.n;
+	const bool ok = pos != kNoEntry && end != kNoEntry && end >= pos && end <= A.n;
+	A.f_in_off[f] = ok ? pos : 0;
+	A.f_in_len[f] = ok ? end - pos : 0;
+	A.f_out_off[f] = (uint64_t)f * kFragment;
+	A.f_out_cap[f] = min(kFragment, A.ulength - f * kFragment);
+	if (!ok)
+		atomicOr(&A.flags[SF_REFUSED], 4u); /* an element straddles a multiple of 32 KiB */
+}
+
+extern "C" __global__ void __launch_bounds__(256) snappy_stream_verdict(StreamArgs A)
+{
+	__shared__ uint32_t bad;
+	const uint32_t tid = threadIdx.x;
+	if (tid == 0)
+		bad = (A.flags[SF_REFUSED] != 0 || A.flags[SF_CHANGED] != 0 || A.flags[SF_CHANGED + 1] != 0 ||
+		       A.flags[SF_END] != A.n ||
+		       A.total[0] != A.ulength) ? 1u : 0u;
+	__syncthreads();
+	uint32_t mine = 0;
+	for (uint32_t f = tid; f < A.nfrag; f += 256)
+		if (A.f_status[f] != CSNAPPY_E_OK || A.f_produced[f] != A.f_out_cap[f])
+			mine = 1;
+	if (mine)
+		atomicOr(&bad, 1u);
+	__syncthreads();
+	if (tid == 0) {
+		A.flags[SF_VERDICT] = bad ? 0u : 1u;
+		if (!bad) {
+			A.status[0] = CSNAPPY_E_OK;
+			A.produced[0] = A.ulength;
+		}
+	}
+}
+
+/* descriptors of the one-block slow path; flags; "no boundary found yet" */
+extern "C" __global__ void __launch_bounds__(256) snappy_stream_setup(StreamArgs A)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < A.nfrag)
+		A.frag_pos[i] = kNoEntry;
+	if (i == 0) {
+		A.one_off[0] = 0;
+		A.one_off[1] = 0;
+		A.one_len[0] = A.n;
+		A.one_len[1] = A.ulength;
+		for (uint32_t k = 0; k < SF_COUNT; ++k)
+			A.flags[k] = 0;
+		A.total[0] = 0;
 	}
 }
 
@@ -2297,6 +2824,7 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 	A.produced = d_produced;
 	A.nblocks = nblocks;
 	A.mode = mode;
+	A.skip_if = nullptr;
 	Timer t(st);
 	t.start();
 	hipLaunchKernelGGL(snappy_decompress_blocks, dim3(nblocks), dim3(64), 0, st, A);
@@ -2304,6 +2832,145 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 	if (!hip_ok(hipGetLastError(), "launch snappy_decompress_blocks"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	return 0;
+}
+
+namespace {
+/* workspace of the stream call: index arrays, fragment descriptors, slow-path descriptor, flags */
+struct StreamPlan {
+	StreamArgs A;
+	size_t total;
+	bool indexed; /* false: lengths for which the index is not defined, one-wave decode only */
+};
+
+StreamPlan plan_stream(uint32_t n, uint32_t ulength, uint8_t *ws)
+{
+	StreamPlan P;
+	memset(&P.A, 0, sizeof(P.A));
+	P.indexed = n > 0 && ulength > 0 && n < 0xffff0000u && ulength < 0xffff0000u;
+	const size_t nseg = P.indexed ? ((size_t)n + kSegBytes - 1) / kSegBytes : 0;
+	const size_t nfrag = P.indexed ? ((size_t)ulength + kFragment - 1) / kFragment : 0;
+	size_t at = 0;
+	auto take = [&](size_t bytes) {
+		uint8_t *p = ws + at;
+		at += (bytes + 15) & ~(size_t)15;
+		return p;
+	};
+	P.A.n = n;
+	P.A.ulength = ulength;
+	P.A.nseg = (uint32_t)nseg;
+	P.A.nfrag = (uint32_t)nfrag;
+	P.A.tagmask = reinterpret_cast<uint64_t *>(take(nseg * 64 * 8));
+	P.A.winout = reinterpret_cast<uint32_t *>(take(nseg * 64 * 4));
+	P.A.truemask = reinterpret_cast<uint64_t *>(take(nseg * 64 * 8));
+	P.A.trueout = reinterpret_cast<uint32_t *>(take(nseg * 64 * 4));
+	P.A.seg_out = reinterpret_cast<uint64_t *>(take(nseg * 8));
+	P.A.seg_exit = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.seg_xesz = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.seg_used = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.seg_guess = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.memo_entry = reinterpret_cast<uint32_t *>(take(nseg * 8));
+	P.A.memo_leave = reinterpret_cast<uint32_t *>(take(nseg * 8));
+	P.A.memo_lesz = reinterpret_cast<uint32_t *>(take(nseg * 8));
+	P.A.seg_entry = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.f_in_off = reinterpret_cast<uint64_t *>(take(nfrag * 8));
+	P.A.f_out_off = reinterpret_cast<uint64_t *>(take(nfrag * 8));
+	P.A.frag_pos = reinterpret_cast<uint32_t *>(take(nfrag * 4));
+	P.A.f_in_len = reinterpret_cast<uint32_t *>(take(nfrag * 4));
+	P.A.f_out_cap = reinterpret_cast<uint32_t *>(take(nfrag * 4));
+	P.A.f_produced = reinterpret_cast<uint32_t *>(take(nfrag * 4));
+	P.A.f_status = reinterpret_cast<int32_t *>(take(nfrag * 4));
+	P.A.one_off = reinterpret_cast<uint64_t *>(take(16));
+	P.A.total = reinterpret_cast<uint64_t *>(take(8));
+	P.A.one_len = reinterpret_cast<uint32_t *>(take(8));
+	P.A.flags = reinterpret_cast<uint32_t *>(take(4 * SF_COUNT));
+	P.total = at;
+	return P;
+}
+} // namespace
+
+size_t csnappy_hip_decompress_stream_workspace_size(uint32_t in_len, uint32_t ulength)
+{
+	return plan_stream(in_len, ulength, nullptr).total;
+}
+
+int csnappy_hip_decompress_stream(const void *d_in, uint32_t in_len, uint32_t ulength, void *d_out,
+				  int32_t *d_status, uint32_t *d_produced, void *d_workspace,
+				  size_t workspace_bytes, void *stream)
+{
+	StreamPlan P = plan_stream(in_len, ulength, static_cast<uint8_t *>(d_workspace));
+	if (!d_workspace || workspace_bytes < P.total || (reinterpret_cast<uintptr_t>(d_workspace) & 15))
+		return CSNAPPY_HIP_E_ARG;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	StreamArgs &S = P.A;
+	S.in = static_cast<const uint8_t *>(d_in);
+	S.status = d_status;
+	S.produced = d_produced;
+	DecompressArgs D;
+	D.in = S.in;
+	D.out = static_cast<uint8_t *>(d_out);
+	D.mode = CSNAPPY_HIP_FRAGMENT;
+	{
+		Timer t(st);
+		t.start();
+		hipLaunchKernelGGL(snappy_stream_setup, dim3(S.nfrag / 256 + 1), dim3(256), 0, st, S);
+		if (P.indexed) {
+			hipLaunchKernelGGL(snappy_stream_index, dim3(S.nseg), dim3(64), 0, st, S);
+			for (S.round = 0; S.round < kStreamRounds; ++S.round) {
+				hipLaunchKernelGGL(snappy_stream_chain, dim3(1), dim3(64), 0, st, S);
+				hipLaunchKernelGGL(snappy_stream_settle, dim3(S.nseg), dim3(64), 0, st, S);
+			}
+			hipLaunchKernelGGL(snappy_stream_scan, dim3(1), dim3(1024), 0, st, S);
+			hipLaunchKernelGGL(snappy_stream_bounds, dim3(S.nseg), dim3(64), 0, st, S);
+			hipLaunchKernelGGL(snappy_stream_describe, dim3((S.nfrag + 255) / 256), dim3(256), 0, st, S);
+		}
+		t.stop(3);
+	}
+	if (P.indexed) {
+		/* the fragments, as independent no-header blocks */
+		D.in_off = S.f_in_off;
+		D.in_len = S.f_in_len;
+		D.out_off = S.f_out_off;
+		D.out_cap = S.f_out_cap;
+		D.status = S.f_status;
+		D.produced = S.f_produced;
+		D.nblocks = S.nfrag;
+		D.skip_if = nullptr;
+		Timer t(st);
+		t.start();
+		hipLaunchKernelGGL(snappy_decompress_blocks, dim3(S.nfrag), dim3(64), 0, st, D);
+		hipLaunchKernelGGL(snappy_stream_verdict, dim3(1), dim3(256), 0, st, S);
+		t.stop(2);
+	}
+	/* the whole body with one wave, unless the verdict let the fragments stand */
+	D.in_off = S.one_off;
+	D.in_len = S.one_len;
+	D.out_off = S.one_off + 1;
+	D.out_cap = S.one_len + 1;
+	D.status = d_status;
+	D.produced = d_produced;
+	D.nblocks = 1;
+	D.skip_if = S.flags + SF_VERDICT;
+	{
+		Timer t(st);
+		t.start();
+		hipLaunchKernelGGL(snappy_decompress_blocks, dim3(1), dim3(64), 0, st, D);
+		t.stop(2);
+	}
+	if (!hip_ok(hipGetLastError(), "launch stream decompress"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	return 0;
+}
+
+int csnappy_hip_decompress_stream_took_fast_path(const void *d_workspace, uint32_t in_len, uint32_t ulength,
+						  void *stream)
+{
+	StreamPlan P = plan_stream(in_len, ulength, static_cast<uint8_t *>(const_cast<void *>(d_workspace)));
+	uint32_t v = 0;
+	if (!hip_ok(hipMemcpyAsync(&v, P.A.flags + SF_VERDICT, 4, hipMemcpyDeviceToHost,
+				   static_cast<hipStream_t>(stream)), "read verdict") ||
+	    !hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "sync"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	return (int)v;
 }
 
 int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_len,

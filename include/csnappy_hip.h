@@ -82,6 +82,33 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 				 int32_t *d_status, uint32_t *d_produced, int mode, void *stream);
 
 /*
+ * Decompress ONE stream body of any length with the whole device.  Same contract
+ * as csnappy_decompress_noheader(d_in, in_len, d_out, &ulength) (csnappy_decompress.c:319-387)
+ * with *dst_len = ulength on entry: d_status[0] receives the reference's return code,
+ * d_produced[0] the bytes produced when it is 0.  csnappy_decompress (:390-415) is this call
+ * after the length header has been parsed (the header's value is `ulength`).
+ *
+ * A pre-pass indexes the tags of the body with one wave per 4 KiB and looks for the elements that
+ * start at multiples of 32 KiB of output; streams written by csnappy_compress have one at each
+ * (csnappy_compress.c:585-616 restarts the matcher there), and their fragments are then decoded
+ * as independent blocks by csnappy_hip_decompress_batch's kernel.  Whenever that does not work out
+ * -- a foreign compressor that copies across 32 KiB, a damaged stream, any fragment that does not
+ * decode cleanly to exactly its size -- the body is decoded by one wave as in the batch call, so
+ * the status and the bytes are the reference's for every input; only the time differs.
+ * Asynchronous on `stream`.  The workspace (csnappy_hip_decompress_stream_workspace_size bytes,
+ * 16-byte aligned, about in_len / 5 + 40 bytes per 32 KiB of output) holds nothing across calls.
+ * in_len and ulength must be below 2^32 - 2^16.
+ */
+size_t csnappy_hip_decompress_stream_workspace_size(uint32_t in_len, uint32_t ulength);
+int csnappy_hip_decompress_stream(const void *d_in, uint32_t in_len, uint32_t ulength, void *d_out,
+				  int32_t *d_status, uint32_t *d_produced, void *d_workspace,
+				  size_t workspace_bytes, void *stream);
+/* 1 if the last csnappy_hip_decompress_stream call on this workspace kept the fragments' result,
+ * 0 if the one-wave decode produced it (waits for `stream`; for tests and tools) */
+int csnappy_hip_decompress_stream_took_fast_path(const void *d_workspace, uint32_t in_len,
+						  uint32_t ulength, void *stream);
+
+/*
  * Pack the slot-strided output of csnappy_hip_compress_batch into one dense stream:
  * block b's d_out_len[b] bytes go to d_dense + d_dense_off[b] (the caller supplies the exclusive
  * scan of the lengths).  This is what the reference's callers do with their own memcpy after
@@ -102,6 +129,7 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
  * csnappy_hip_get_kernel_timing() waits for the recorded events, returns the summed duration
  * (milliseconds) and the number of launches per kernel since the previous read, and resets.
  * slots: [0] snappy_parse_fragments (all its launches)  [1] snappy_emit_blocks  [2] snappy_decompress_blocks
+ *        [3] the stream call's index kernels (snappy_stream_*), one count per call
  */
 void csnappy_hip_set_kernel_timing(int enable);
 void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4]);

@@ -335,6 +335,132 @@ def test_foreign_stream_features(torch, chk):
 
 
 # -------------------------------------------------------------------------------------------------
+# one long stream on many waves: csnappy_hip_decompress_stream
+# -------------------------------------------------------------------------------------------------
+def _stream_call(torch, stream, chk):
+    """csnappy_decompress semantics through the stream call: -> (status, bytes, took_fast_path);
+    the header is parsed on the host like csnappy_host.c does."""
+    hdr, ulen = chk.get_uncompressed_length(stream)
+    assert hdr > 0
+    body = torch.from_numpy(np.frombuffer(stream[hdr:], dtype=np.uint8).copy()).cuda() if len(stream) > hdr \
+        else torch.zeros(0, dtype=torch.uint8, device="cuda")
+    d_out = torch.full((ulen + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    st, produced, fast = api.decompress_stream(body, ulen, d_out)
+    out = d_out.cpu().numpy()
+    assert (out[ulen:] == 0xA5).all(), "wrote past the expected length"
+    return st, bytes(out[:produced]) if st == 0 else b"", fast
+
+
+def _long_input(seed, nbytes, urls):
+    """text, urls-like, incompressible and near-constant stretches, so that the stream has short
+    and 32 KiB literals, dense copies, and segments the parse flies over"""
+    rng = np.random.default_rng(seed)
+    parts, have = [], 0
+    while have < nbytes:
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(20000, 200000))
+        if kind == 0:
+            part = api.generate_host(api.WG_TEXT, seed + have, 0, 1, n)
+        elif kind == 1:
+            at = int(rng.integers(0, len(urls) - n))
+            part = np.frombuffer(urls[at:at + n], dtype=np.uint8)
+        elif kind == 2:
+            part = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 3:
+            part = api.generate_host(api.WG_LOW, seed + have, 0, 1, n)
+        else:
+            part = np.full(n, int(rng.integers(0, 256)), dtype=np.uint8)
+        parts.append(part)
+        have += n
+    return np.concatenate(parts)[:nbytes].tobytes()
+
+
+@pytest.mark.parametrize("nbytes", [3 * 32768, 7 * 32768 + 1, 1 << 20, 5 * (1 << 20) + 12345])
+def test_long_stream_is_decoded_fragment_by_fragment(torch, chk, urls, nbytes):
+    """A stream written by csnappy_compress has an element at every multiple of 32 KiB of output:
+    the stream call must find them all and let the fragments' result stand -- same bytes as the
+    checker's csnappy_decompress."""
+    data = _long_input(nbytes, nbytes, urls)
+    stream = chk.compress(data, 16)
+    st, out, fast = _stream_call(torch, stream, chk)
+    assert st == 0 and out == data
+    assert fast, "the index did not find the fragments of a csnappy stream"
+    # and through the plain csnappy.h call (which routes long bodies to the stream call)
+    assert api.decompress(stream, len(data)) == (0, data)
+
+
+def test_long_foreign_stream_falls_back_to_one_wave(torch, chk):
+    """Copies across 32 KiB of output (legal Snappy, never written by csnappy): the fragments cannot
+    be decoded apart, the one-wave result is the answer."""
+    rng = np.random.default_rng(9)
+    first = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()
+
+    def lit(b):
+        n = len(b) - 1
+        k = (n.bit_length() + 7) // 8
+        return (bytes([n << 2]) if n < 60 else bytes([(59 + k) << 2]) + n.to_bytes(k, "little")) + b
+    body, want = lit(first), bytearray(first)
+    for i in range(3000):  # 4-byte-offset copies reaching far back
+        off = int(rng.integers(40000, 290000))
+        body += bytes([3 | (63 << 2)]) + off.to_bytes(4, "little")
+        for _ in range(64):
+            want.append(want[-off])
+    hdr = b""
+    v = len(want)
+    while v >= 128:
+        hdr += bytes([v & 127 | 128])
+        v >>= 7
+    stream = hdr + bytes([v]) + body
+    rc, ref = chk.decompress(stream, len(want))
+    assert rc == 0 and ref == bytes(want)
+    st, out, fast = _stream_call(torch, stream, chk)
+    assert st == 0 and out == bytes(want) and not fast
+    assert api.decompress(stream, len(want)) == (0, bytes(want))
+
+
+def test_damaged_long_streams_report_what_the_reference_reports(torch, chk, urls):
+    """Byte flips, cuts and a wrong length header in a 1 MiB stream: status and bytes of the stream
+    call equal the checker's for every one of them (most go through the one-wave decode; a flip
+    inside literal bytes leaves the structure intact and stays on the fragments)."""
+    data = _long_input(77, 1 << 20, urls)
+    good = bytearray(chk.compress(data, 16))
+    rng = np.random.default_rng(5)
+    hdr = chk.get_uncompressed_length(bytes(good))[0]
+    cases = []
+    for _ in range(24):
+        s = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            s[int(rng.integers(hdr, len(s)))] = int(rng.integers(0, 256))
+        cases.append(bytes(s))
+    for _ in range(6):
+        cases.append(bytes(good[:int(rng.integers(hdr + 140000, len(good)))]))
+    cases.append(bytes(good) + b"\x00")           # one more (1-byte literal) element than the length allows
+    cases.append(bytes(good) + bytes(200000))      # ... and many more
+    from test_oracle import _body_has_truncated_tag
+    fasts = 0
+    for s in cases:
+        if _body_has_truncated_tag(s, hdr):
+            continue  # the reference reads past the input there: undefined (SURVEY Appendix C)
+        rc, ref = chk.decompress(s, len(data))
+        st, out, fast = _stream_call(torch, s, chk)
+        assert st == rc, (st, rc)
+        if rc == 0:
+            assert out == ref[:len(out)] and len(out) <= len(data)
+            # a stream that decodes cleanly but produces less than its header says is CSNAPPY_E_OK
+            # in the reference (csnappy_decompress.c:384-386); produced is then what noheader reports
+            assert chk.decompress_noheader(s[hdr:], len(data))[1] == len(out)
+        fasts += fast
+    assert 0 < fasts < len(cases)
+
+
+def test_stream_call_on_short_and_empty_bodies(torch, chk):
+    for data in (b"", b"a", b"abc" * 100, bytes(5000)):
+        stream = chk.compress(data, 16)
+        st, out, _ = _stream_call(torch, stream, chk)
+        assert st == 0 and out == data
+
+
+# -------------------------------------------------------------------------------------------------
 # full-size properties (BASELINE config sizes are far beyond what the oracle can check in
 # seconds: check size-independent properties there)
 # -------------------------------------------------------------------------------------------------
@@ -505,6 +631,30 @@ def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
     d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
     blocks, _, _ = gpu_compress(torch, d_in.cpu().numpy(), [g["block"]] * g["nblocks"], g["p"], g["mode"])
     assert sha(b"".join(blocks)) == g["sha256"]
+
+
+def test_block_longer_than_promised_is_refused_not_corrupted(torch, chk):
+    """in_len[b] > max_in_len violates the batch call's precondition (the workspace is sized by
+    max_in_len): that block gets out_len = 0xffffffff and its slot is not touched, its neighbours are
+    compressed as usual."""
+    rng = np.random.default_rng(3)
+    lens = [4096, 9000, 4096]
+    host = rng.integers(0, 4, sum(lens), dtype=np.uint8)
+    b = api.Batch(lens)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.full((b.out_bytes + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(api.workspace_size(3, 4096) + 256, dtype=torch.uint8, device="cuda")
+    ws = ws[(-ws.data_ptr()) % 256:]
+    api.compress_batch(d_in, b.d_in_off, b.d_in_len, 4096, d_out, b.d_out_off, b.d_out_len, 13, api.STREAM, ws)
+    torch.cuda.synchronize()
+    out, out_len = d_out.cpu().numpy(), b.d_out_len.cpu().numpy().astype(np.uint32)
+    assert out_len[1] == 0xFFFFFFFF
+    o1 = int(b.out_off[1])
+    assert (out[o1:o1 + int(b.slot[1])] == 0xA5).all()
+    for i in (0, 2):
+        x = host[int(b.in_off[i]):int(b.in_off[i]) + lens[i]]
+        o = int(b.out_off[i])
+        assert bytes(out[o:o + int(out_len[i])]) == chk.compress(x, 13)
 
 
 def _slot_sharing_cases(seed, count):
