@@ -1786,6 +1786,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
  *            front leaves, so that most exits are known before the parse comes through.
  *   scan     exclusive sum of the segments' output bytes.
  *   bounds   one wave per segment looks for elements that start at a multiple of 32 KiB of output.
+ *   grain    all multiples found: 32 KiB fragments.  Every other one: the stream comes from a
+ *            Snappy with 64 KiB blocks, pairs of fragments are decoded as one block.
  *   describe one thread per fragment turns the boundaries into batch descriptors.
  * Then snappy_decompress_blocks decodes the fragments as independent no-header blocks, a verdict
  * kernel accepts the result only if every fragment decoded cleanly to exactly its size, the
@@ -1832,7 +1834,7 @@ struct StreamArgs {
  * of round r + 1 reads it and resets the other one.  (Reading and resetting the same word in one
  * kernel is not safe: the compiler reads such a word through the scalar cache, and that load is
  * not ordered against the vector store behind it.) */
-enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_ACTIVE = 3, SF_ROUNDS = 4, SF_CHANGED = 6, SF_RESUME = 8, SF_COUNT = 12 };
+enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_ACTIVE = 3, SF_ROUNDS = 4, SF_GRAIN = 5, SF_CHANGED = 6, SF_RESUME = 8, SF_COUNT = 12 };
 constexpr uint32_t kStreamRounds = 16;
 
 struct TagAt {
@@ -2201,20 +2203,48 @@ extern "C" __global__ void __launch_bounds__(64) snappy_stream_bounds(StreamArgs
 	}
 }
 
+/* Which multiples of 32 KiB of output have an element starting at them: all of them (a csnappy
+ * stream, or Snappy 1.0's 32 KiB blocks), or at least every other one (the 64 KiB blocks of later
+ * Snappy versions, whose copies stay inside their block just the same)?  SF_GRAIN = 1, 2, or 0. */
+extern "C" __global__ void __launch_bounds__(256) snappy_stream_grain(StreamArgs A)
+{
+	__shared__ uint32_t miss;
+	const uint32_t tid = threadIdx.x;
+	if (tid == 0)
+		miss = 0;
+	__syncthreads();
+	uint32_t mine = 0;
+	for (uint32_t f = tid; f < A.nfrag; f += 256)
+		if (A.frag_pos[f] == kNoEntry)
+			mine |= (f & 1) ? 1u : 2u;
+	if (mine)
+		atomicOr(&miss, mine);
+	__syncthreads();
+	if (tid == 0) {
+		const uint32_t grain = miss == 0 ? 1u : miss == 1 ? 2u : 0u;
+		A.flags[SF_GRAIN] = grain;
+		if (!grain)
+			atomicOr(&A.flags[SF_REFUSED], 4u); /* an element straddles a block boundary */
+	}
+}
+
 extern "C" __global__ void __launch_bounds__(256) snappy_stream_describe(StreamArgs A)
 {
 	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
 	if (f >= A.nfrag)
 		return;
-	const uint32_t pos = A.frag_pos[f];
-	const uint32_t end = f + 1 < A.nfrag ? A.frag_pos[f + 1] : A.n;
-	const bool ok = pos != kNoEntry && end != kNoEntry && end >= pos && end <= A.n;
+	const uint32_t grain = A.flags[SF_GRAIN];
+	/* with 64 KiB blocks the even fragments carry two fragments' worth, the odd ones nothing */
+	const bool used = grain != 0 && f % grain == 0;
+	const uint32_t pos = used ? A.frag_pos[f] : 0;
+	const uint32_t end = !used ? 0 : f + grain < A.nfrag ? A.frag_pos[f + grain] : A.n;
+	const bool ok = used && end >= pos && end <= A.n;
 	A.f_in_off[f] = ok ? pos : 0;
 	A.f_in_len[f] = ok ? end - pos : 0;
 	A.f_out_off[f] = (uint64_t)f * kFragment;
-	A.f_out_cap[f] = min(kFragment, A.ulength - f * kFragment);
-	if (!ok)
-		atomicOr(&A.flags[SF_REFUSED], 4u); /* an element straddles a multiple of 32 KiB */
+	A.f_out_cap[f] = ok ? min(grain * kFragment, A.ulength - f * kFragment) : 0;
+	if (used && !ok)
+		atomicOr(&A.flags[SF_REFUSED], 4u);
 }
 
 extern "C" __global__ void __launch_bounds__(256) snappy_stream_verdict(StreamArgs A)
@@ -2921,6 +2951,7 @@ int csnappy_hip_decompress_stream(const void *d_in, uint32_t in_len, uint32_t ul
 			}
 			hipLaunchKernelGGL(snappy_stream_scan, dim3(1), dim3(1024), 0, st, S);
 			hipLaunchKernelGGL(snappy_stream_bounds, dim3(S.nseg), dim3(64), 0, st, S);
+			hipLaunchKernelGGL(snappy_stream_grain, dim3(1), dim3(256), 0, st, S);
 			hipLaunchKernelGGL(snappy_stream_describe, dim3((S.nfrag + 255) / 256), dim3(256), 0, st, S);
 		}
 		t.stop(3);

@@ -418,6 +418,38 @@ def test_long_foreign_stream_falls_back_to_one_wave(torch, chk):
     assert api.decompress(stream, len(want)) == (0, bytes(want))
 
 
+def test_long_stream_with_64k_blocks_is_decoded_block_by_block(torch, chk):
+    """Snappy since 1.1 compresses 64 KiB blocks: copies reach back up to 64 KiB, elements start
+    at every multiple of 64 KiB of output but not at the odd multiples of 32 KiB.  The index pairs
+    the fragments up."""
+    rng = np.random.default_rng(21)
+    body, want = b"", bytearray()
+    for blk in range(9):
+        size = 65536 if blk < 8 else 30001
+        nlit = min(40000, size)
+        lit = rng.integers(0, 256, nlit, dtype=np.uint8).tobytes()
+        body += bytes([(59 + 2) << 2]) + (nlit - 1).to_bytes(2, "little") + lit
+        start = len(want)
+        want += lit
+        while len(want) - start < size:
+            ln = min(64, size - (len(want) - start))
+            off = int(rng.integers(33000, 39000))
+            body += bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+            for _ in range(ln):
+                want.append(want[-off])
+    hdr, v = b"", len(want)
+    while v >= 128:
+        hdr += bytes([v & 127 | 128])
+        v >>= 7
+    stream = hdr + bytes([v]) + body
+    rc, ref = chk.decompress(stream, len(want))
+    assert rc == 0 and ref == bytes(want)
+    st, out, fast = _stream_call(torch, stream, chk)
+    assert st == 0 and out == bytes(want)
+    assert fast, "64 KiB blocks were not recognised"
+    assert api.decompress(stream, len(want)) == (0, bytes(want))
+
+
 def test_damaged_long_streams_report_what_the_reference_reports(torch, chk, urls):
     """Byte flips, cuts and a wrong length header in a 1 MiB stream: status and bytes of the stream
     call equal the checker's for every one of them (most go through the one-wave decode; a flip
