@@ -1768,22 +1768,24 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
  * fragmenting (csnappy_compress.c:585-616): csnappy_compress restarts its table every 32 KiB of
  * input, so no copy reaches across a multiple of 32 KiB of OUTPUT and an element starts at each of
  * them.  The pre-pass below finds those elements without decoding anything:
- *   index    one wave per 4 KiB segment of the compressed bytes parses it speculatively from its
- *            first byte (which is usually not a tag): per 64-byte window the tags it met and the
- *            bytes they produce.  Parses that start at different bytes fall into step after a few
- *            elements, and from a common tag on they are the same parse.
- *   chain    one wave strings the segments together.  An element that reaches beyond its segment
- *            (a long literal) is followed exactly, its successor's header is read on the spot.
- *            Otherwise the parse leaves segment k where settle saw it leave when entered at this
- *            very byte, and failing that where the speculative parse left it -- an assumption.
+ *   index    one wave per 4 KiB segment of the compressed bytes.  (a) It parses the segment from
+ *            its first byte, which is usually not a tag: per 64-byte window the tags met and the
+ *            bytes they produce, and where this speculative parse leaves the segment.  Parses
+ *            that start at different bytes fall into step after a few elements, and from a
+ *            common tag on they are one parse.  (b) It settles the matter for EVERY byte of the
+ *            segment: each byte, read as a tag, points at the next one; pointer doubling in LDS
+ *            (12 sweeps over 4096 u16) turns that into "the last tag inside the segment on the
+ *            parse that starts here".  The table goes to HBM, and with it the length of the
+ *            prefix of the segment in which every byte ends on the speculative parse's last tag:
+ *            a parse entering there leaves with the speculative one, no questions asked.
+ *   chain    one wave strings the segments together, exactly, in one pass: an element that
+ *            reaches beyond its segment (a long literal) is followed and its successor's header
+ *            read on the spot; an entry inside the safe prefix leaves with the speculative parse
+ *            (no memory access at all: the common case); any other entry looks its last tag up
+ *            in the segment's table and reads two headers (literal-heavy data, where the
+ *            speculative parse wanders through literal bytes and never meets the true one).
  *   settle   one wave per segment walks the parse from its entry until it meets the speculative
- *            one, corrects the windows in front of that point and notes "entered here, leaves
- *            there" (with the speculative parse if they met, else on its own: literal bytes parse
- *            to anything).  If chain had assumed otherwise, both run again: up to kStreamRounds
- *            rounds, skipped once nothing changes.  A round gets at least one more segment right,
- *            and at the fixed point every entry is the true one, by induction from the first.
- *            Segments a round's parse does not touch are walked from where their neighbour in
- *            front leaves, so that most exits are known before the parse comes through.
+ *            one and corrects the windows in front of that point.
  *   scan     exclusive sum of the segments' output bytes.
  *   bounds   one wave per segment looks for elements that start at a multiple of 32 KiB of output.
  *   grain    all multiples found: 32 KiB fragments.  Every other one: the stream comes from a
@@ -1808,15 +1810,13 @@ struct StreamArgs {
 	uint32_t *winout;    /* [nseg * 64] bytes they produce (saturating) */
 	uint64_t *truemask;  /* [nseg * 64] the same of the true parse (settle) */
 	uint32_t *trueout;
+	uint16_t *last_tag;  /* [nseg * 4096] last tag inside the segment on the parse that starts at each byte */
 	/* per segment [nseg]: */
 	uint32_t *seg_exit;  /* where the speculative parse left it ... */
 	uint32_t *seg_xesz;  /* ... and the input bytes of the element that starts there */
-	uint32_t *seg_entry; /* where this round's parse enters it, or kNoEntry */
-	uint32_t *seg_used;  /* where chain took this round's parse to leave it */
-	uint32_t *seg_guess; /* where the parse would enter coming out of the segment in front, or kNoEntry */
-	/* what settle found: "entered at .entry, the parse leaves at .leave, where an element of .lesz
-	 * input bytes starts" -- [0..nseg) for an entry on a round's parse, [nseg..2 nseg) for a guess */
-	uint32_t *memo_entry, *memo_leave, *memo_lesz;
+	uint32_t *seg_safe;  /* bytes at its start from which every parse leaves with the speculative one */
+	uint32_t *seg_entry; /* where the true parse enters it, or kNoEntry */
+	uint32_t *seg_leave; /* ... and leaves it */
 	uint64_t *seg_out;   /* [nseg] bytes the segment produces; after the scan, its output offset */
 	uint32_t *frag_pos;  /* [nfrag] input position of the element that starts fragment f */
 	uint64_t *f_in_off, *f_out_off; /* [nfrag] batch descriptors of the fragments ... */
@@ -1824,18 +1824,12 @@ struct StreamArgs {
 	int32_t *f_status;
 	uint64_t *one_off;   /* ... and [2] zeros: offsets of the one-block slow path */
 	uint32_t *one_len;   /* [2] n, ulength: its in_len and out_cap */
-	uint32_t *flags;     /* SF_*: refused, end of the true parse, verdict (1 = fragments stand), round state */
-	uint32_t round;
+	uint32_t *flags;     /* SF_*: refused, end of the true parse, verdict (1 = fragments stand), grain */
 	uint64_t *total;     /* [1] bytes the parse produces */
 	int32_t *status;     /* the caller's result */
 	uint32_t *produced;
 };
-/* SF_CHANGED / SF_RESUME have one slot per round parity: settle of round r writes slot r & 1, chain
- * of round r + 1 reads it and resets the other one.  (Reading and resetting the same word in one
- * kernel is not safe: the compiler reads such a word through the scalar cache, and that load is
- * not ordered against the vector store behind it.) */
-enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_ACTIVE = 3, SF_ROUNDS = 4, SF_GRAIN = 5, SF_CHANGED = 6, SF_RESUME = 8, SF_COUNT = 12 };
-constexpr uint32_t kStreamRounds = 16;
+enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_GRAIN = 3, SF_COUNT = 4 };
 
 struct TagAt {
 	uint32_t esz; /* bytes the element takes in the input (saturating) */
@@ -1848,17 +1842,18 @@ struct TagAt {
 DEVINL TagAt tag_at(const uint8_t *src, uint32_t n, uint32_t at, const uint16_t *ctab)
 {
 	uint32_t b0 = 0, tr = 0;
-	if (at + 8 <= n) {
+	const uint32_t room = at < n ? n - at : 0u; /* (`at` may be a saturated 0xffffffff: no at + k here) */
+	if (room >= 8) {
 		uint64_t v;
 		__builtin_memcpy(&v, src + at, 8);
 		b0 = (uint32_t)v & 0xff;
 		tr = (uint32_t)(v >> 8);
 	} else {
-		if (at < n)
+		if (room > 0)
 			b0 = src[at];
 #pragma unroll
-		for (int kk = 0; kk < 4; ++kk)
-			if (at + 1 + kk < n)
+		for (uint32_t kk = 0; kk < 4; ++kk)
+			if (1 + kk < room)
 				tr |= (uint32_t)src[at + 1 + kk] << (8 * kk);
 	}
 	const uint32_t e = ctab[b0];
@@ -1910,20 +1905,26 @@ DEVINL uint32_t window_out(uint64_t mask, uint32_t l, uint32_t lane)
 extern "C" __global__ void __launch_bounds__(64) snappy_stream_index(StreamArgs A)
 {
 	__shared__ uint16_t ctab[256];
+	__shared__ uint16_t last[kSegBytes]; /* first: the next tag from each byte (itself if that lies outside) */
 	const uint32_t lane = threadIdx.x, seg = blockIdx.x;
 	fill_tag_table(ctab, lane);
 	const uint32_t seg_lo = seg * kSegBytes;
+	const uint32_t seg_len = min(kSegBytes, A.n - seg_lo);
 	uint64_t pos = seg_lo; /* next tag of the speculative parse */
 	uint64_t my_mask = 0;
 	uint32_t my_out = 0;
 	TagAt t = tag_at(A.in, A.n, seg_lo + lane, ctab);
 	for (uint32_t w = 0; w < 64; ++w) {
 		const uint32_t base = seg_lo + 64 * w;
-		if (base >= A.n)
-			break;
+		const uint32_t p = 64 * w + lane;
+		if (base >= A.n) {
+			last[p] = (uint16_t)p;
+			continue;
+		}
 		const TagAt cur = t;
 		if (w + 1 < 64 && base + 64 < A.n)
 			t = tag_at(A.in, A.n, base + 64 + lane, ctab); /* in flight during the walk */
+		last[p] = (uint16_t)((uint64_t)p + cur.esz < seg_len ? p + cur.esz : p);
 		const uint32_t wlim = min(64u, A.n - base);
 		if (pos >= (uint64_t)base + wlim)
 			continue;
@@ -1943,88 +1944,65 @@ extern "C" __global__ void __launch_bounds__(64) snappy_stream_index(StreamArgs 
 	if (lane == 0) {
 		A.seg_exit[seg] = leave;
 		A.seg_xesz[seg] = next.esz;
-		A.memo_entry[seg] = kNoEntry;
-		A.memo_entry[A.nseg + seg] = kNoEntry;
 	}
-}
-
-/* what is known about the segments of one 64-segment chunk, one per lane */
-struct ChainChunk {
-	uint32_t sx, sz;     /* speculative exit */
-	uint32_t te, tl, tz; /* settle's note for an entry on a round's parse */
-	uint32_t ge, gl, gz; /* ... and for a guessed entry */
-};
-
-DEVINL ChainChunk chain_load(const StreamArgs &A, uint32_t c, uint32_t lane)
-{
-	const uint32_t k = c + lane < A.nseg ? c + lane : 0u;
-	ChainChunk C;
-	C.sx = A.seg_exit[k];
-	C.sz = A.seg_xesz[k];
-	C.te = A.memo_entry[k];
-	C.tl = A.memo_leave[k];
-	C.tz = A.memo_lesz[k];
-	C.ge = A.memo_entry[A.nseg + k];
-	C.gl = A.memo_leave[A.nseg + k];
-	C.gz = A.memo_lesz[A.nseg + k];
-	return C;
-}
-
-/* where the parse leaves a segment as far as anyone knows */
-DEVINL uint32_t chain_best(const ChainChunk &C)
-{
-	return C.te != kNoEntry ? C.tl : C.ge != kNoEntry ? C.gl : C.sx;
+	/* pointer doubling, in place (a pointer only ever moves along its own parse, so reading a
+	 * value another lane has just advanced is as good): elements take >= 2 bytes, a parse has at
+	 * most 2048 of them in a segment, 11 sweeps would do */
+	wave_lds_fence();
+	for (uint32_t sweep = 0; sweep < 12; ++sweep) {
+		bool moved = false;
+		for (uint32_t i = 0; i < 64; ++i) {
+			const uint32_t p = 64 * i + lane;
+			const uint32_t v = last[p], vv = last[v];
+			moved |= vv != v;
+			last[p] = (uint16_t)vv;
+		}
+		wave_lds_fence();
+		if (!ballot64(moved))
+			break;
+	}
+	/* the safe prefix: bytes from which the parse ends on the speculative parse's last tag */
+	const uint32_t spec_last = last[0];
+	uint32_t safe = kSegBytes;
+	for (uint32_t i = 0; i < 64; ++i) {
+		const uint64_t off = ballot64(last[64 * i + lane] != spec_last);
+		if (off) {
+			safe = 64 * i + first_lane(off);
+			break;
+		}
+	}
+	if (lane == 0)
+		A.seg_safe[seg] = safe;
+	uint4 *dst = reinterpret_cast<uint4 *>(A.last_tag + (size_t)seg * kSegBytes);
+	const uint4 *src = reinterpret_cast<const uint4 *>(last);
+	for (uint32_t i = lane; i < kSegBytes * 2 / 16; i += 64)
+		dst[i] = src[i];
 }
 
 extern "C" __global__ void __launch_bounds__(64) snappy_stream_chain(StreamArgs A)
 {
 	__shared__ uint16_t ctab[256];
 	const uint32_t lane = threadIdx.x;
-	/* rounds after the first run only while the previous settle changed something, and pick the
-	 * parse up at the first segment it changed (everything in front has been confirmed) */
-	const uint32_t mine = A.round & 1, last = mine ^ 1;
-	const bool active = A.round == 0 || A.flags[SF_CHANGED + last] != 0;
-	const uint32_t first = A.round == 0 ? 0u : A.flags[SF_RESUME + last];
-	if (lane == 0) {
-		A.flags[SF_ACTIVE] = active ? 1u : 0u;
-		A.flags[SF_CHANGED + mine] = 0;
-		A.flags[SF_RESUME + mine] = 0xffffffffu;
-		if (active)
-			A.flags[SF_ROUNDS] = A.round + 1;
-	}
-	if (!active || first >= A.nseg)
-		return;
 	fill_tag_table(ctab, lane);
-	uint32_t e = first == 0 ? 0u : A.seg_entry[first]; /* the parse is here ... */
-	uint32_t esz = rdlane(tag_at(A.in, A.n, e, ctab).esz, 0); /* ... at an element of this many bytes */
-	const uint32_t c0 = first & ~63u;
-	uint32_t front_leaves = 0;
-	if (c0 > 0)
-		front_leaves = rdlane(chain_best(chain_load(A, c0 - 1, lane)), 0);
-	ChainChunk N = chain_load(A, c0, lane);
-	for (uint32_t c = c0; c < A.nseg; c += 64) {
-		const ChainChunk C = N;
+	uint32_t e = 0; /* the parse starts at the first byte of the body ... */
+	uint32_t esz = rdlane(tag_at(A.in, A.n, 0, ctab).esz, 0); /* ... with an element of this many bytes */
+	const auto load = [&](uint32_t c, uint32_t &sx, uint32_t &sz, uint32_t &sf) {
+		const uint32_t k = c + lane < A.nseg ? c + lane : 0u;
+		sx = A.seg_exit[k];
+		sz = A.seg_xesz[k];
+		sf = A.seg_safe[k];
+	};
+	uint32_t nsx, nsz, nsf;
+	load(0, nsx, nsz, nsf);
+	for (uint32_t c = 0; c < A.nseg; c += 64) {
+		const uint32_t sx = nsx, sz = nsz, sf = nsf;
 		if (c + 64 < A.nseg)
-			N = chain_load(A, c + 64, lane); /* in flight while this chunk is walked */
-		const bool have = c + lane < A.nseg;
-		const uint32_t k = c + lane;
-		/* Segments this round's parse will not touch are walked by settle all the same, from
-		 * where the segment in front leaves as far as anyone knows: most exits are then known
-		 * by the time the parse does come through. */
-		{
-			const uint32_t best = chain_best(C);
-			const uint32_t up = (uint32_t)__shfl_up((int)best, 1);
-			const uint32_t from = lane == 0 ? front_leaves : up;
-			const uint64_t lo64 = (uint64_t)k * kSegBytes;
-			const uint64_t hi64 = lo64 + kSegBytes < A.n ? lo64 + kSegBytes : A.n;
-			if (have)
-				A.seg_guess[k] = (k > 0 && from >= lo64 && from < hi64) ? from : kNoEntry;
-			front_leaves = rdlane(best, 63);
-		}
-		uint32_t ent = kNoEntry, used = 0;
+			load(c + 64, nsx, nsz, nsf); /* in flight while this chunk is walked */
+		uint32_t ent = kNoEntry, lv = 0;
 		const uint32_t m = min(64u, A.nseg - c);
-		for (uint32_t j = c == c0 ? first - c0 : 0u; j < m; ++j) {
-			const uint64_t hi64 = (uint64_t)(c + j + 1) * kSegBytes;
+		for (uint32_t j = 0; j < m; ++j) {
+			const uint32_t lo = (c + j) * kSegBytes;
+			const uint64_t hi64 = (uint64_t)lo + kSegBytes;
 			const uint32_t hi = hi64 < A.n ? (uint32_t)hi64 : A.n;
 			if (e >= hi)
 				continue; /* inside an element that started earlier */
@@ -2035,22 +2013,22 @@ extern "C" __global__ void __launch_bounds__(64) snappy_stream_chain(StreamArgs 
 				/* the element at the entry reaches beyond the segment: follow it */
 				e = after > 0xffffffffull ? 0xffffffffu : (uint32_t)after;
 				esz = rdlane(tag_at(A.in, A.n, e, ctab).esz, 0);
-			} else if (e == rdlane(C.te, j)) {
-				e = rdlane(C.tl, j);
-				esz = rdlane(C.tz, j);
-			} else if (e == rdlane(C.ge, j)) {
-				e = rdlane(C.gl, j);
-				esz = rdlane(C.gz, j);
+			} else if (e - lo < rdlane(sf, j)) {
+				e = rdlane(sx, j);
+				esz = rdlane(sz, j);
 			} else {
-				e = rdlane(C.sx, j);
-				esz = rdlane(C.sz, j);
+				/* anywhere else: the table knows the last tag on this parse; two headers to read */
+				const uint32_t lt = lo + A.last_tag[(size_t)(c + j) * kSegBytes + (e - lo)];
+				const uint64_t out = (uint64_t)lt + rdlane(tag_at(A.in, A.n, lt, ctab).esz, 0);
+				e = out > 0xffffffffull ? 0xffffffffu : (uint32_t)out;
+				esz = rdlane(tag_at(A.in, A.n, e, ctab).esz, 0);
 			}
 			if (lane == j)
-				used = e;
+				lv = e;
 		}
-		if (have && k >= first) {
-			A.seg_entry[k] = ent;
-			A.seg_used[k] = used;
+		if (c + lane < A.nseg) {
+			A.seg_entry[c + lane] = ent;
+			A.seg_leave[c + lane] = lv;
 		}
 	}
 	if (lane == 0)
@@ -2061,15 +2039,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_stream_settle(StreamArgs
 {
 	__shared__ uint16_t ctab[256];
 	const uint32_t lane = threadIdx.x, seg = blockIdx.x;
-	if (!A.flags[SF_ACTIVE])
-		return;
-	uint32_t entry = A.seg_entry[seg];
-	const bool flown_over = entry == kNoEntry;
-	if (flown_over) {
-		entry = A.seg_guess[seg];
-		if (entry == A.memo_entry[A.nseg + seg])
-			entry = kNoEntry; /* walked from there before */
-	}
+	const uint32_t entry = A.seg_entry[seg];
 	uint64_t my_mask = A.tagmask[(size_t)seg * 64 + lane];
 	uint32_t my_out = A.winout[(size_t)seg * 64 + lane];
 	if (entry == kNoEntry) {
@@ -2113,23 +2083,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_stream_settle(StreamArgs
 				my_out = out;
 			}
 		}
-		/* where the parse leaves: with the speculative one if they met, else on its own */
+		/* cross-check of the two ways to the segment's exit (chain's and this walk's) */
 		const uint32_t leave = met ? A.seg_exit[seg] : pos > 0xffffffffull ? 0xffffffffu : (uint32_t)pos;
-		const uint32_t lesz = met ? A.seg_xesz[seg] : tag_at(A.in, A.n, leave, ctab).esz;
-		if (lane == 0) {
-			const uint32_t slot = flown_over ? A.nseg + seg : seg;
-			A.memo_entry[slot] = entry;
-			A.memo_leave[slot] = leave;
-			A.memo_lesz[slot] = lesz;
-			if (!flown_over && leave != A.seg_used[seg]) {
-				A.flags[SF_CHANGED + (A.round & 1)] = 1; /* the segments behind may be entered elsewhere */
-				atomicMin(&A.flags[SF_RESUME + (A.round & 1)], seg);
-			}
-		}
-	}
-	if (flown_over) {
-		my_mask = 0;
-		my_out = 0;
+		if (lane == 0 && leave != A.seg_leave[seg])
+			atomicOr(&A.flags[SF_REFUSED], 1u);
 	}
 	A.truemask[(size_t)seg * 64 + lane] = my_mask;
 	A.trueout[(size_t)seg * 64 + lane] = my_out;
@@ -2252,8 +2209,7 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stream_verdict(StreamAr
 	__shared__ uint32_t bad;
 	const uint32_t tid = threadIdx.x;
 	if (tid == 0)
-		bad = (A.flags[SF_REFUSED] != 0 || A.flags[SF_CHANGED] != 0 || A.flags[SF_CHANGED + 1] != 0 ||
-		       A.flags[SF_END] != A.n ||
+		bad = (A.flags[SF_REFUSED] != 0 || A.flags[SF_END] != A.n ||
 		       A.total[0] != A.ulength) ? 1u : 0u;
 	__syncthreads();
 	uint32_t mine = 0;
@@ -2896,11 +2852,9 @@ StreamPlan plan_stream(uint32_t n, uint32_t ulength, uint8_t *ws)
 	P.A.seg_out = reinterpret_cast<uint64_t *>(take(nseg * 8));
 	P.A.seg_exit = reinterpret_cast<uint32_t *>(take(nseg * 4));
 	P.A.seg_xesz = reinterpret_cast<uint32_t *>(take(nseg * 4));
-	P.A.seg_used = reinterpret_cast<uint32_t *>(take(nseg * 4));
-	P.A.seg_guess = reinterpret_cast<uint32_t *>(take(nseg * 4));
-	P.A.memo_entry = reinterpret_cast<uint32_t *>(take(nseg * 8));
-	P.A.memo_leave = reinterpret_cast<uint32_t *>(take(nseg * 8));
-	P.A.memo_lesz = reinterpret_cast<uint32_t *>(take(nseg * 8));
+	P.A.seg_safe = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.seg_leave = reinterpret_cast<uint32_t *>(take(nseg * 4));
+	P.A.last_tag = reinterpret_cast<uint16_t *>(take(nseg * kSegBytes * 2));
 	P.A.seg_entry = reinterpret_cast<uint32_t *>(take(nseg * 4));
 	P.A.f_in_off = reinterpret_cast<uint64_t *>(take(nfrag * 8));
 	P.A.f_out_off = reinterpret_cast<uint64_t *>(take(nfrag * 8));
@@ -2945,10 +2899,8 @@ int csnappy_hip_decompress_stream(const void *d_in, uint32_t in_len, uint32_t ul
 		hipLaunchKernelGGL(snappy_stream_setup, dim3(S.nfrag / 256 + 1), dim3(256), 0, st, S);
 		if (P.indexed) {
 			hipLaunchKernelGGL(snappy_stream_index, dim3(S.nseg), dim3(64), 0, st, S);
-			for (S.round = 0; S.round < kStreamRounds; ++S.round) {
-				hipLaunchKernelGGL(snappy_stream_chain, dim3(1), dim3(64), 0, st, S);
-				hipLaunchKernelGGL(snappy_stream_settle, dim3(S.nseg), dim3(64), 0, st, S);
-			}
+			hipLaunchKernelGGL(snappy_stream_chain, dim3(1), dim3(64), 0, st, S);
+			hipLaunchKernelGGL(snappy_stream_settle, dim3(S.nseg), dim3(64), 0, st, S);
 			hipLaunchKernelGGL(snappy_stream_scan, dim3(1), dim3(1024), 0, st, S);
 			hipLaunchKernelGGL(snappy_stream_bounds, dim3(S.nseg), dim3(64), 0, st, S);
 			hipLaunchKernelGGL(snappy_stream_grain, dim3(1), dim3(256), 0, st, S);

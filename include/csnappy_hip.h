@@ -90,13 +90,14 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
  *
  * A pre-pass indexes the tags of the body with one wave per 4 KiB and looks for the elements that
  * start at multiples of 32 KiB of output; streams written by csnappy_compress have one at each
- * (csnappy_compress.c:585-616 restarts the matcher there), and their fragments are then decoded
- * as independent blocks by csnappy_hip_decompress_batch's kernel.  Whenever that does not work out
+ * (csnappy_compress.c:585-616 restarts the matcher there; Snappy's own 32 KiB or 64 KiB blocks
+ * are recognised the same way), and their fragments are then decoded as independent blocks by
+ * csnappy_hip_decompress_batch's kernel.  Whenever that does not work out
  * -- a foreign compressor that copies across 32 KiB, a damaged stream, any fragment that does not
  * decode cleanly to exactly its size -- the body is decoded by one wave as in the batch call, so
  * the status and the bytes are the reference's for every input; only the time differs.
  * Asynchronous on `stream`.  The workspace (csnappy_hip_decompress_stream_workspace_size bytes,
- * 16-byte aligned, about in_len / 5 + 40 bytes per 32 KiB of output) holds nothing across calls.
+ * 16-byte aligned, about 2.4 x in_len + 40 bytes per 32 KiB of output) holds nothing across calls.
  * in_len and ulength must be below 2^32 - 2^16.
  */
 size_t csnappy_hip_decompress_stream_workspace_size(uint32_t in_len, uint32_t ulength);

@@ -587,6 +587,15 @@ def test_soak_slice_decode(torch):
     assert batches >= 2 and streams > 100, (batches, streams, kind)
 
 
+def test_soak_slice_stream(torch):
+    """A fixed-seed slice of tests/soak_stream_gpu.py: long streams through the stream call, sound
+    (must be decoded fragment by fragment) and damaged (flips, cuts, splices, removed / doubled
+    stretches, wrong length): status, produced length and bytes against the reference."""
+    import soak_stream_gpu
+    checked, fasts, kind = soak_stream_gpu.soak(15.0, seed=20261003)
+    assert checked > 20 and 0 < fasts < checked, (checked, fasts, kind)
+
+
 def test_compact_stream_equals_concatenation(torch, urls):
     from csnappy_amd import shard
     data = np.frombuffer(urls, dtype=np.uint8)

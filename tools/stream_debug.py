@@ -13,11 +13,11 @@ def layout(n, ulen):
     nseg, nfrag = (n + 4095) // 4096, (ulen + 32767) // 32768
     at, out = 0, {}
     for name, size in (("tagmask", nseg * 512), ("winout", nseg * 256), ("truemask", nseg * 512), ("trueout", nseg * 256),
-                       ("seg_out", nseg * 8), ("seg_exit", nseg * 4), ("seg_xesz", nseg * 4), ("seg_used", nseg * 4), ("seg_guess", nseg * 4),
-                       ("memo_entry", nseg * 8), ("memo_leave", nseg * 8), ("memo_lesz", nseg * 8),
-                       ("seg_entry", nseg * 4), ("f_in_off", nfrag * 8), ("f_out_off", nfrag * 8), ("frag_pos", nfrag * 4),
+                       ("seg_out", nseg * 8), ("seg_exit", nseg * 4), ("seg_xesz", nseg * 4), ("seg_safe", nseg * 4),
+                       ("seg_leave", nseg * 4), ("last_tag", nseg * 8192), ("seg_entry", nseg * 4),
+                       ("f_in_off", nfrag * 8), ("f_out_off", nfrag * 8), ("frag_pos", nfrag * 4),
                        ("f_in_len", nfrag * 4), ("f_out_cap", nfrag * 4), ("f_produced", nfrag * 4), ("f_status", nfrag * 4),
-                       ("one_off", 16), ("total", 8), ("one_len", 8), ("flags", 48)):
+                       ("one_off", 16), ("total", 8), ("one_len", 8), ("flags", 16)):
         out[name] = (at, size)
         at += (size + 15) & ~15
     return out, at, nseg, nfrag
@@ -53,11 +53,13 @@ def main():
     get = lambda name, dt: h[lay[name][0]:lay[name][0] + lay[name][1]].view(dt)
     flags = get("flags", np.uint32)
     print(f"rc {rc} status/produced {res.cpu().tolist()}  body {n} B, {nseg} segments; expects {ulen} B, {nfrag} fragments")
-    print(f"refused bits {flags[0]} (1 never met, 2 huge element, 4 missing boundary)  parse ends at {flags[1]} (body {n})  "
-          f"verdict {flags[2]}  still changing {flags[6] | flags[7]}  total out {get('total', np.uint64)[0]}")
-    print("rounds of chain + settle that ran:", flags[4])
-    used, ex, ent = get("seg_used", np.uint32), get("seg_exit", np.uint32), get("seg_entry", np.uint32)
-    print("segments the parse does not leave with the speculative one:", int(((used != ex) & (ent != 0xFFFFFFFF)).sum()), "of", nseg)
+    print(f"refused bits {flags[0]} (1 chain and settle disagree, 2 huge element, 4 missing boundary)  parse ends at {flags[1]} "
+          f"(body {n})  verdict {flags[2]}  grain {flags[3]}  total out {get('total', np.uint64)[0]}")
+    ent, safe = get("seg_entry", np.uint32), get("seg_safe", np.uint32)
+    inside = ent != 0xFFFFFFFF
+    rel = (ent.astype(np.int64) - np.arange(nseg) * 4096)[inside]
+    print(f"segments entered {int(inside.sum())} of {nseg}; entries beyond the safe prefix (table path or long element): "
+          f"{int((rel >= safe[inside]).sum())}; median safe prefix {int(np.median(safe))} B")
     # time: the stream call against the same stream on one wave (the batch call with one block)
     def timed(fn, reps=5):
         fn()
