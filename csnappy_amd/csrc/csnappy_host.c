@@ -220,10 +220,14 @@ out:
  * spreads it over the device when its fragments can be told apart (include/csnappy_hip.h) */
 #define STREAM_CALL_MIN_BODY (128u * 1024u)
 
+static uint32_t expansion_bound(uint32_t n);
+
 static int decompress_stream_on_device(const char *body, uint32_t body_len, char *dst, uint32_t olen)
 {
 	struct desc d;
 	size_t ws_need;
+	/* the kernels never write past what the body can expand to, whatever the header claims */
+	const uint32_t alloc = olen < expansion_bound(body_len) ? olen : expansion_bound(body_len);
 	int status = CSNAPPY_E_HIP_UNAVAILABLE;
 	char *dd;
 
@@ -231,7 +235,7 @@ static int decompress_stream_on_device(const char *body, uint32_t body_len, char
 	if (ctx_init() < 0)
 		goto out;
 	ws_need = csnappy_hip_decompress_stream_workspace_size(body_len, olen);
-	if (grow(&g.in, (size_t)body_len + 64) || grow(&g.out, (size_t)olen + 64) ||
+	if (grow(&g.in, (size_t)body_len + 64) || grow(&g.out, (size_t)alloc + 64) ||
 	    grow(&g.ws, ws_need) || grow(&g.desc, sizeof(d)))
 		goto out;
 	dd = (char *)g.desc.p;
