@@ -60,14 +60,16 @@ except Exception as e:  # noqa
 
 # per BATCH CALL figures (what bench.py's HIP events measure).  A compress batch call launches the
 # parser up to three times (two dense table sizes, then the global table; two of them under one
-# kernel name) and the emit kernel once; bench.py calls the compress batch once more than the
-# decompress batch (the bit-exactness check).  So: batch calls of an operation = launches of the
-# kernel that runs exactly once per call (emit / decompress), and every kernel's TOTAL over the
-# run is divided by that.
+# kernel name) and the emit kernel once, per chunk; bench.py calls the compress batch once more
+# than the decompress batch (the bit-exactness check).  So: batch calls = decompress launches
+# (+ 1 for compress), and every kernel's TOTAL over the run is divided by that.
 try:
     def batches_of(fam, counts):
-        once = "snappy_emit_blocks" if fam in ("snappy_parse_fragments", "snappy_emit_blocks") else fam
-        return max(counts.get(once, 0), 1)
+        # decompress is one launch per batch call; compress launches once per chunk of 32 768
+        # fragments (several chunks for a GiB of 4 KiB pages) and is called once more than
+        # decompress (the bit-exactness check)
+        dec = max(counts.get("snappy_decompress_blocks", 0), 1)
+        return dec + 1 if fam in ("snappy_parse_fragments", "snappy_emit_blocks") else max(counts.get(fam, 0), 1)
     calls = {n: k["calls"] for n, k in summary["kernels"].items()}
     for name, k in summary["kernels"].items():
         f = summary["per_batch"].setdefault(family(name), {"ms": 0.0, "launches_per_batch": 0.0})
