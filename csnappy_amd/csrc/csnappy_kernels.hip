@@ -814,7 +814,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 							for (;;) {
 								if (PROF)
 									n_hops++;
-								taken |= 1ull << i;
+								asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */
 								last = i;
 								t = rdlane(nx, i);
 								if (t >= 64)
