@@ -222,12 +222,16 @@ out:
 
 static uint32_t expansion_bound(uint32_t n);
 
-static int decompress_stream_on_device(const char *body, uint32_t body_len, char *dst, uint32_t olen)
+static int decompress_stream_on_device(const char *body, uint32_t body_len, char *dst, uint32_t room,
+				       uint32_t *produced)
 {
 	struct desc d;
 	size_t ws_need;
-	/* the kernels never write past what the body can expand to, whatever the header claims */
-	const uint32_t alloc = olen < expansion_bound(body_len) ? olen : expansion_bound(body_len);
+	/* Room beyond what the body can expand to is never used, whatever the header or the caller
+	 * claims: with the room clamped to that, status and bytes are the same and the device
+	 * buffers stay proportional to the input. */
+	const uint32_t olen = room < expansion_bound(body_len) ? room : expansion_bound(body_len);
+	const uint32_t alloc = olen;
 	int status = CSNAPPY_E_HIP_UNAVAILABLE;
 	char *dd;
 
@@ -253,6 +257,7 @@ static int decompress_stream_on_device(const char *body, uint32_t body_len, char
 	    hipMemcpy(dst, g.out.p, d.produced, hipMemcpyDeviceToHost) != hipSuccess)
 		goto out;
 	status = d.status;
+	*produced = d.produced;
 out:
 	pthread_mutex_unlock(&g.mu);
 	return status;
@@ -276,8 +281,8 @@ int csnappy_decompress(const char *src, uint32_t src_len, char *dst, uint32_t ds
 		return CSNAPPY_E_HEADER_BAD;
 	if (olen > dst_len)
 		return CSNAPPY_E_OUTPUT_INSUF;
-	if (src_len - (uint32_t)hdr >= STREAM_CALL_MIN_BODY && olen < 0xffff0000u && src_len < 0xffff0000u)
-		return decompress_stream_on_device(src + hdr, src_len - (uint32_t)hdr, dst, olen);
+	if (src_len - (uint32_t)hdr >= STREAM_CALL_MIN_BODY && src_len < 0xffff0000u)
+		return decompress_stream_on_device(src + hdr, src_len - (uint32_t)hdr, dst, olen, &produced);
 	/* the kernel never writes past the header length, nor can the body expand past its bound */
 	alloc = olen < expansion_bound(src_len) ? olen : expansion_bound(src_len);
 	return decompress_on_device(src, src_len, dst, dst_len, alloc, &produced, CSNAPPY_HIP_STREAM);
@@ -289,8 +294,9 @@ int csnappy_decompress_noheader(const char *src, uint32_t src_len, char *dst, ui
 	/* *dst_len is "space available" and may be huge: the device buffer is sized by what src_len
 	 * bytes can expand to, not by it */
 	uint32_t alloc = *dst_len < expansion_bound(src_len) ? *dst_len : expansion_bound(src_len);
-	int rc = decompress_on_device(src, src_len, dst, *dst_len, alloc, &produced,
-				      CSNAPPY_HIP_FRAGMENT);
+	int rc = src_len >= STREAM_CALL_MIN_BODY && src_len < 0xffff0000u
+			 ? decompress_stream_on_device(src, src_len, dst, *dst_len, &produced)
+			 : decompress_on_device(src, src_len, dst, *dst_len, alloc, &produced, CSNAPPY_HIP_FRAGMENT);
 	if (rc == CSNAPPY_E_OK)
 		*dst_len = produced;
 	return rc;

@@ -1804,7 +1804,7 @@ constexpr uint32_t kHugeOut = 1u << 24;    /* window outputs saturate here; no f
 
 struct StreamArgs {
 	const uint8_t *in;   /* the body: the stream without its length header */
-	uint32_t n, ulength; /* its bytes; the bytes it is expected to produce */
+	uint32_t n, ulength; /* its bytes; the room for what it produces (*dst_len of the reference call) */
 	uint32_t nseg, nfrag;
 	uint64_t *tagmask;   /* [nseg * 64] tags met in each window */
 	uint32_t *winout;    /* [nseg * 64] bytes they produce (saturating) */
@@ -1829,7 +1829,7 @@ struct StreamArgs {
 	int32_t *status;     /* the caller's result */
 	uint32_t *produced;
 };
-enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_GRAIN = 3, SF_COUNT = 4 };
+enum { SF_REFUSED = 0, SF_END = 1, SF_VERDICT = 2, SF_GRAIN = 3, SF_NFRAG = 4, SF_COUNT = 8 };
 
 struct TagAt {
 	uint32_t esz; /* bytes the element takes in the input (saturating) */
@@ -2167,19 +2167,25 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stream_grain(StreamArgs
 {
 	__shared__ uint32_t miss;
 	const uint32_t tid = threadIdx.x;
+	/* the fragments the parse's output fills (A.nfrag is the host's upper bound).  A parse that
+	 * yields nothing, or more than the caller has room for (-3 somewhere), is the slow path's. */
+	const uint64_t total = A.total[0];
+	const bool fits = total > 0 && total <= A.ulength;
+	const uint32_t nfrag = fits ? min((uint32_t)((total + kFragment - 1) / kFragment), A.nfrag) : 0u;
 	if (tid == 0)
 		miss = 0;
 	__syncthreads();
 	uint32_t mine = 0;
-	for (uint32_t f = tid; f < A.nfrag; f += 256)
+	for (uint32_t f = tid; f < nfrag; f += 256)
 		if (A.frag_pos[f] == kNoEntry)
 			mine |= (f & 1) ? 1u : 2u;
 	if (mine)
 		atomicOr(&miss, mine);
 	__syncthreads();
 	if (tid == 0) {
-		const uint32_t grain = miss == 0 ? 1u : miss == 1 ? 2u : 0u;
+		const uint32_t grain = !fits ? 0u : miss == 0 ? 1u : miss == 1 ? 2u : 0u;
 		A.flags[SF_GRAIN] = grain;
+		A.flags[SF_NFRAG] = nfrag;
 		if (!grain)
 			atomicOr(&A.flags[SF_REFUSED], 4u); /* an element straddles a block boundary */
 	}
@@ -2190,16 +2196,17 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stream_describe(StreamA
 	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
 	if (f >= A.nfrag)
 		return;
-	const uint32_t grain = A.flags[SF_GRAIN];
+	const uint32_t grain = A.flags[SF_GRAIN], nfrag = A.flags[SF_NFRAG];
 	/* with 64 KiB blocks the even fragments carry two fragments' worth, the odd ones nothing */
-	const bool used = grain != 0 && f % grain == 0;
+	const bool used = grain != 0 && f < nfrag && f % grain == 0;
 	const uint32_t pos = used ? A.frag_pos[f] : 0;
-	const uint32_t end = !used ? 0 : f + grain < A.nfrag ? A.frag_pos[f + grain] : A.n;
+	const uint32_t end = !used ? 0 : f + grain < nfrag ? A.frag_pos[f + grain] : A.n;
 	const bool ok = used && end >= pos && end <= A.n;
+	const uint64_t left = A.total[0] - (uint64_t)f * kFragment; /* (used: f * 32 KiB < total) */
 	A.f_in_off[f] = ok ? pos : 0;
 	A.f_in_len[f] = ok ? end - pos : 0;
 	A.f_out_off[f] = (uint64_t)f * kFragment;
-	A.f_out_cap[f] = ok ? min(grain * kFragment, A.ulength - f * kFragment) : 0;
+	A.f_out_cap[f] = ok ? (uint32_t)min((uint64_t)grain * kFragment, left) : 0;
 	if (used && !ok)
 		atomicOr(&A.flags[SF_REFUSED], 4u);
 }
@@ -2209,8 +2216,7 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stream_verdict(StreamAr
 	__shared__ uint32_t bad;
 	const uint32_t tid = threadIdx.x;
 	if (tid == 0)
-		bad = (A.flags[SF_REFUSED] != 0 || A.flags[SF_END] != A.n ||
-		       A.total[0] != A.ulength) ? 1u : 0u;
+		bad = (A.flags[SF_REFUSED] != 0 || A.flags[SF_END] != A.n) ? 1u : 0u;
 	__syncthreads();
 	uint32_t mine = 0;
 	for (uint32_t f = tid; f < A.nfrag; f += 256)
@@ -2223,7 +2229,7 @@ extern "C" __global__ void __launch_bounds__(256) snappy_stream_verdict(StreamAr
 		A.flags[SF_VERDICT] = bad ? 0u : 1u;
 		if (!bad) {
 			A.status[0] = CSNAPPY_E_OK;
-			A.produced[0] = A.ulength;
+			A.produced[0] = (uint32_t)A.total[0];
 		}
 	}
 }
@@ -2834,7 +2840,9 @@ StreamPlan plan_stream(uint32_t n, uint32_t ulength, uint8_t *ws)
 	memset(&P.A, 0, sizeof(P.A));
 	P.indexed = n > 0 && ulength > 0 && n < 0xffff0000u && ulength < 0xffff0000u;
 	const size_t nseg = P.indexed ? ((size_t)n + kSegBytes - 1) / kSegBytes : 0;
-	const size_t nfrag = P.indexed ? ((size_t)ulength + kFragment - 1) / kFragment : 0;
+	/* fragments: as many as the room allows, or as the body can fill (a 3-byte copy yields 64 bytes) */
+	const uint64_t can_fill = (uint64_t)n * 22 + 64;
+	const size_t nfrag = P.indexed ? (size_t)(((ulength < can_fill ? ulength : can_fill) + kFragment - 1) / kFragment) : 0;
 	size_t at = 0;
 	auto take = [&](size_t bytes) {
 		uint8_t *p = ws + at;

@@ -83,18 +83,20 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 
 /*
  * Decompress ONE stream body of any length with the whole device.  Same contract
- * as csnappy_decompress_noheader(d_in, in_len, d_out, &ulength) (csnappy_decompress.c:319-387)
- * with *dst_len = ulength on entry: d_status[0] receives the reference's return code,
- * d_produced[0] the bytes produced when it is 0.  csnappy_decompress (:390-415) is this call
- * after the length header has been parsed (the header's value is `ulength`).
+ * as csnappy_decompress_noheader(d_in, in_len, d_out, &ulength) (csnappy_decompress.c:319-387):
+ * `ulength` is *dst_len on entry (the room in d_out), d_status[0] receives the reference's return
+ * code, d_produced[0] the bytes produced when it is 0 (*dst_len on exit; it may be less than
+ * ulength).  csnappy_decompress (:390-415) is this call after the length header has been parsed
+ * (the header's value is `ulength`).
  *
  * A pre-pass indexes the tags of the body with one wave per 4 KiB and looks for the elements that
  * start at multiples of 32 KiB of output; streams written by csnappy_compress have one at each
  * (csnappy_compress.c:585-616 restarts the matcher there; Snappy's own 32 KiB or 64 KiB blocks
  * are recognised the same way), and their fragments are then decoded as independent blocks by
  * csnappy_hip_decompress_batch's kernel.  Whenever that does not work out
- * -- a foreign compressor that copies across 32 KiB, a damaged stream, any fragment that does not
- * decode cleanly to exactly its size -- the body is decoded by one wave as in the batch call, so
+ * -- a foreign compressor that copies across 32 KiB, a damaged stream, a stream that yields more
+ * than ulength, any fragment that does not decode cleanly to exactly its size -- the body is
+ * decoded by one wave as in the batch call, so
  * the status and the bytes are the reference's for every input; only the time differs.
  * Asynchronous on `stream`.  The workspace (csnappy_hip_decompress_stream_workspace_size bytes,
  * 16-byte aligned, about 2.4 x in_len + 40 bytes per 32 KiB of output) holds nothing across calls.

@@ -385,8 +385,17 @@ def test_long_stream_is_decoded_fragment_by_fragment(torch, chk, urls, nbytes):
     st, out, fast = _stream_call(torch, stream, chk)
     assert st == 0 and out == data
     assert fast, "the index did not find the fragments of a csnappy stream"
-    # and through the plain csnappy.h call (which routes long bodies to the stream call)
+    # and through the plain csnappy.h calls (which route long bodies to the stream call); the
+    # no-header form with more room than the body fills reports what was produced
     assert api.decompress(stream, len(data)) == (0, data)
+    hdr = chk.get_uncompressed_length(stream)[0]
+    assert api.decompress_noheader(stream[hdr:], len(data) + 12345) == (0, len(data), data)
+    assert api.decompress_noheader(stream[hdr:], len(data) - 1)[0] == chk.decompress_noheader(stream[hdr:], len(data) - 1)[0] == -3
+    # room for more than the header says is room like any other: still fragment by fragment
+    body = torch.from_numpy(np.frombuffer(stream[hdr:], dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(len(data) + 70000, dtype=torch.uint8, device="cuda")
+    st, produced, fast = api.decompress_stream(body, len(data) + 70000, d_out)
+    assert (st, produced, fast) == (0, len(data), True) and bytes(d_out[:produced].cpu().numpy()) == data
 
 
 def test_long_foreign_stream_falls_back_to_one_wave(torch, chk):
