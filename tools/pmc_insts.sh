@@ -10,7 +10,7 @@ args="--steps 2 --warmup 1 --no-cpu-baseline $*"
 i=0
 for grp in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/g$i -o run -- python3 bench.py $args > $out/bench_$i.json 2> $out/bench_$i.err
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $out/g$i -o run -- python3 bench.py $args > $out/bench_$i.json 2> $out/bench_$i.err
 done
 python3 - "$out" > $out/summary.txt <<'PY'
 import csv, glob, os, sys
