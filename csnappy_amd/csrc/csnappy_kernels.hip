@@ -2,33 +2,39 @@
  * csnappy_kernels.hip -- Snappy raw-block codec for MI355X (gfx950, wave64), from scratch.
  *
  * What the kernels replace in the reference (file:line into the reference tree):
- *   snappy_compress_fragments   csnappy_compress_fragment          csnappy_compress.c:469-606
- *                               Hash/HashBytes                     :228-236
- *                               FindMatchLength                    :252-295
- *                               EmitLiteral / EmitCopy(LessThan64) :332-415
- *                               fragment loop + table-size pick    :636-654
- *   snappy_stitch_blocks        the `compressed = p` pointer chain :633-651 (fragment k+1 starts
- *                               where fragment k ended) + encode_varint32 :46-73
- *   snappy_decompress_blocks    csnappy_decompress_noheader        csnappy_decompress.c:319-387
- *                               SAW__Append* / IncrementalCopy*    :200-317
+ *   snappy_parse_fragments*     csnappy_compress_fragment, the probe loop   csnappy_compress.c:469-606
+ *                               Hash/HashBytes                              :228-236
+ *                               FindMatchLength                             :252-295
+ *                               fragment loop + table-size pick             :636-654
+ *   snappy_emit_blocks          EmitLiteral / EmitCopy(LessThan64)          :332-415
+ *                               encode_varint32 + the `compressed = p` chain :46-73, :633-651
+ *   snappy_decompress_blocks    csnappy_decompress_noheader                 csnappy_decompress.c:319-387
+ *                               SAW__Append* / IncrementalCopy*             :200-317
  *                               csnappy_get_uncompressed_length / csnappy_decompress :45-71,394-411
+ *   snappy_stream_*             the same two calls on ONE long stream: a tag index finds the
+ *                               fragments the compressor's 32 KiB restarts left (:585-616), which
+ *                               snappy_decompress_blocks then decodes in parallel
+ *   snappy_compact_stream       the caller's memcpy of each block behind the last
+ *                               (block_compressor.c:316-334)
+ *   snappy_crc32c_blocks        masked CRC-32C of the framing format (include/csnappy_frame.h)
  *
  * Design (DESIGN.md has the long form):
- *   - compress: one workgroup of two waves per 32 KiB fragment.  The PARSER wave reproduces the
- *     reference's sequential probe loop exactly, 64 consecutive positions per step: every lane
- *     hashes its 4 bytes, gathers table[h], measures a lane-local match length against its
- *     candidate; a lane that shares a hash slot with an earlier lane of the step (the only way
- *     its table read could be stale) is flagged and resolved from that lane's registers if the
- *     chain of copies -- followed on the scalar unit, six instructions per copy -- ever probes
- *     it.  The EMITTER wave encodes the queued (literal, copy)
- *     records and writes them out with aligned 16 B/lane stores.  The hash table and the window
- *     live in LDS when at least four fragments fit a CU that way, else in global memory.
- *   - decompress: one wave per block; 64 candidate tag positions are decoded in parallel, the
- *     true tag chain is walked on the scalar unit with v_readlane, per-element output offsets
- *     come from a DPP prefix sum, errors are resolved in element order, then literals and
- *     independent copies run one lane per element and dependent copies wave-wide in order.
- *   - no MFMA: this is byte/integer work bound by latency and cache-line gathers, not a
- *     contraction.
+ *   - compress: one wave per 32 KiB fragment reproduces the reference's sequential probe loop
+ *     exactly, 64 consecutive positions per step: every lane hashes its 4 bytes, gathers the
+ *     table entry, measures a lane-local match length against its candidate; a lane that shares
+ *     a hash slot with an earlier lane of the step (the only way its table read could be stale)
+ *     is flagged and resolved from that lane's registers if the chain of copies -- followed on
+ *     the scalar unit -- ever probes it.  The table lives in LDS, indexed by dense bucket ids a
+ *     prologue of the same wave assigns (only slots hit twice can matter); the window is read
+ *     where it lies.  The wave writes 8-byte (literal, copy) records; a separate kernel turns
+ *     the records of a block into bytes, all fragments at their final offsets.
+ *   - decompress: one wave per block, two phases: 64 candidate tag positions are decoded in
+ *     parallel and the true tag chain is walked on the scalar unit until 64 elements are queued;
+ *     then one lane per element: output offsets from a DPP prefix sum, errors resolved in
+ *     element order, literals and independent copies in parallel, copies that read the batch's
+ *     own output in order, all assembled in LDS and flushed with aligned 16 B stores.
+ *   - no MFMA: this is byte/integer work bound by instruction issue, latency and cache-line
+ *     gathers, not a contraction.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
