@@ -2548,6 +2548,15 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 			P.s_shift = (uint32_t)(p - 1) - bits;
 		}
 	} else if (P.tab == TAB_LDS_DENSE) {
+		/* small fragments (pages): a table for every fragment there can be (`most`) leaves 25
+		 * pages per CU; few pages have more than 0.56 x that many buckets, so the first launch
+		 * takes a table of that size (32 pages per CU, the wave limit) and the second one, with
+		 * the full table, the pages that overflowed */
+		uint32_t cap_full = 0;
+		if (!kn.dense_cap && maxfrag < kFragment && cap == most && most >= 1536) {
+			cap_full = cap;
+			cap = ((most * 9 / 16) + 63) & ~63u;
+		}
 		P.dense_cap = cap;
 		const uint32_t scratch = 10u * (slots >> 5); /* prologue: two bitmaps + the prefix */
 		P.lds0 = 2 * cap > scratch ? 2 * cap : scratch;
@@ -2557,8 +2566,13 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		P.sample_min = kn.sample_min;
 		/* fragments with more buckets than the first table get a second try with a larger one
 		 * (fewer fragments per CU) before the global table: URL lists sit at 4.5-5.5 k buckets */
-		if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
+		if (cap_full) {
+			P.cap2 = cap_full;
+			P.fallback = false; /* the second table holds any page */
+		} else if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
 			P.cap2 = kDenseCap2;
+		}
+		if (P.cap2) {
 			P.lds0_2 = 2 * P.cap2 > scratch ? 2 * P.cap2 : scratch;
 			filter_geometry(P.cap2, s_cap, true, &P.s_entries_2, &P.s_shift_2);
 			P.lds_bytes_2 = P.lds0_2 + P.s_entries_2 * 4 * (P.s_shift_2 ? 2 : 1);
