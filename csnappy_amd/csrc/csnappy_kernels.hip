@@ -74,6 +74,8 @@ struct CompressArgs {
 	uint32_t tab_stride;
 	uint32_t lds0;      /* LDS bytes in front of the conflict filters (table / occupancy bitmap) */
 	uint32_t dense_cap; /* entries of the dense LDS table */
+	uint32_t spill_cap; /* buckets beyond those: a per-fragment table in HBM behind the ids (0 = none) */
+	uint32_t spill_off; /* its byte offset inside the fragment's `tabs` region */
 	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
 	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
 	uint32_t only_unparsed; /* skip fragments that already have records (second and later launches) */
@@ -308,6 +310,13 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
 
+	/* TAB_LDS_DENSE: buckets dense_cap.. of this fragment live in a small table in HBM (behind its
+	 * ids).  Fragments just over the LDS table's size -- URL lists sit at 4.3-5.5 k buckets -- are
+	 * then parsed in the same launch, their few high buckets costing a global gather per step,
+	 * instead of all over again with a larger LDS table and fewer fragments per CU. */
+	bool has_spill = false;
+	uint16_t *spill = reinterpret_cast<uint16_t *>(region + A.spill_off);
+
 	if (n >= kMargin) {
 		if (DENSE) {
 			/* ---- prologue: dense bucket ids (see the header comment) ----
@@ -417,12 +426,13 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			}
 			uint32_t nb;
 			uint32_t run = wave_excl_scan(mine, lane, &nb);
-			if (nb > A.dense_cap) {
-				/* more buckets than the LDS table holds: the global-table launch takes it */
+			if (nb > A.dense_cap + A.spill_cap) {
+				/* more buckets than the LDS table and its spill-over hold: a later launch takes it */
 				if (lane == 0)
 					A.rec_cnt[c] = kNoRecords;
 				return;
 			}
+			has_spill = nb > A.dense_cap;
 			for (uint32_t k = 0; k < per; ++k) {
 				const uint32_t w = lane * per + k;
 				if (w < nwords) {
@@ -454,9 +464,15 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 							wids[i + k] = (uint16_t)id[k];
 				}
 			});
+			if (has_spill) {
+				uint4 *z = reinterpret_cast<uint4 *>(spill);
+				for (uint32_t k = lane; k < (A.spill_cap * 2 + 15) / 16; k += 64)
+					z[k] = make_uint4(0, 0, 0, 0);
+			}
 			wave_lds_fence();
-			/* the ids are read back by this wave only (same CU, same L1/L2 path, program order);
-			 * make the stores leave the wave before the first load of them is issued */
+			/* the ids (and the zeroed spill table) are read back by this wave only (same CU, same
+			 * L1/L2 path, program order); make the stores leave the wave before the first load of
+			 * them is issued */
 			if (PROF)
 				tp3 = __builtin_amdgcn_s_memtime();
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -606,9 +622,16 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
 			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
 			uint32_t cand = 0, first_same;
+			/* (dense) my bucket is one of the few beyond the LDS table */
+			const bool spilled = DENSE && tabbed && slot >= A.dense_cap;
 			if (!GTAB) {
-				cand = tab[tabbed ? slot : 0u];
-				cand = tabbed ? cand : 0u;
+				const bool in_lds = tabbed && !spilled;
+				cand = tab[in_lds ? slot : 0u];
+				cand = in_lds ? cand : 0u;
+			}
+			if (DENSE && has_spill && ballot64(spilled)) {
+				const uint32_t g = spill[spilled ? slot - A.dense_cap : 0u];
+				cand = spilled ? g : cand;
 			}
 			wave_lds_fence();
 			first_same = S[key] & 63u; /* lowest lane with my slot key */
@@ -953,11 +976,13 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				if ((dead >> lane) & 1)
 					commit = false;
 			}
-			if (commit) {
+			if (commit && !spilled) {
 				tab[slot] = (uint16_t)(pos_c | (chk << 15));
 				if (GTAB)
 					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
 			}
+			if (DENSE && has_spill && commit && spilled)
+				spill[slot - A.dense_cap] = (uint16_t)(pos_c | (chk << 15));
 			wave_lds_fence();
 			if (PROF)
 				t_commit += __builtin_amdgcn_s_memtime() - t0;
@@ -2419,6 +2444,7 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
 constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
 constexpr uint32_t kDenseCapDefault = 5120; /* entries of the dense LDS table (10 KiB; 14 fragments per CU) */
 constexpr uint32_t kDenseCap2 = 7168;       /* ... of the second dense launch (14 KiB; 10 per CU) */
+constexpr uint32_t kSpillCapDefault = 2048; /* buckets beyond the LDS table kept in HBM (4 KiB per fragment) */
 constexpr uint32_t kSampleMinDefault = 700; /* of 2048 sampled positions (text: ~1400, runs: ~300) */
 constexpr uint32_t kHashLdsMaxBytes = 8192; /* tables up to this size are indexed by the hash in LDS */
 
@@ -2446,10 +2472,13 @@ uint32_t record_cap(uint32_t n)
  *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        entries per conflict filter
  *   CSNAPPY_HIP_WGS_PER_CU 1..32                          cap on fragments in flight per CU
  *   CSNAPPY_HIP_SAMPLE_MIN 0..2048                        dense placement: sampled-distinct threshold
- *                                                         below which a fragment takes the global table */
+ *                                                         below which a fragment takes the global table
+ *   CSNAPPY_HIP_SPILL_CAP  0..8192 (multiple of 64)       dense placement: buckets beyond the LDS table
+ *                                                         kept in HBM (0: a second launch with a larger
+ *                                                         LDS table takes such fragments instead) */
 struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
-	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min;
+	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
 	bool ok;
 };
 
@@ -2468,7 +2497,7 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, true };
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true };
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -2480,6 +2509,7 @@ Knobs read_knobs()
 			k.ok = false;
 	}
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_DENSE_CAP", 256, 16384, &k.dense_cap) && (k.dense_cap & 63) == 0;
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_SPILL_CAP", 0, 8192, &k.spill_cap) && (k.spill_cap & 63) == 0;
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_S_ENTRIES", 64, 4096, &k.s_entries) &&
 	       (k.s_entries & (k.s_entries - 1)) == 0;
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
@@ -2493,6 +2523,7 @@ struct ParsePlan {
 	uint32_t lds0, lds_bytes, dense_cap, s_entries, s_shift;
 	uint32_t sample_min;
 	uint32_t cap2, lds0_2, lds_bytes_2, s_entries_2, s_shift_2; /* second dense launch (0 = none) */
+	uint32_t spill_cap; /* dense: buckets beyond the LDS table, kept in HBM (full fragments only) */
 	bool fallback;      /* a TAB_GLOBAL launch follows for fragments the dense table cannot hold */
 	uint32_t g_lds0, g_lds_bytes, g_s_entries, g_s_shift;
 };
@@ -2569,6 +2600,10 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		if (cap_full) {
 			P.cap2 = cap_full;
 			P.fallback = false; /* the second table holds any page */
+		} else if (maxfrag == kFragment && kn.spill_cap) {
+			/* full fragments: the buckets beyond the LDS table go to HBM in the same launch */
+			P.spill_cap = kn.spill_cap;
+			P.fallback = cap + P.spill_cap < (maxfrag - 3) / 2 || kn.sample_min;
 		} else if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
 			P.cap2 = kDenseCap2;
 		}
@@ -2615,7 +2650,8 @@ uint32_t tab_stride_for(uint32_t maxfrag, const Knobs &kn)
 	const uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
 	const bool global_possible = kn.table == TAB_GLOBAL || (maxfrag > 3 && cap < (maxfrag - 3) / 2) ||
 				     (kn.sample_min && maxfrag == kFragment);
-	return global_possible ? 65536u : (ids < 1024 ? 1024u : ids);
+	const uint32_t spill = maxfrag == kFragment ? kn.spill_cap * 2 : 0; /* behind the ids / the global table */
+	return (global_possible ? 65536u : (ids < 1024 ? 1024u : ids)) + spill;
 }
 
 struct Workspace {
@@ -2741,6 +2777,8 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.rec_cap = W.rec_cap;
 	A.tab_stride = W.tab_stride;
 	A.dense_cap = P.dense_cap;
+	A.spill_cap = P.spill_cap;
+	A.spill_off = W.tab_stride - P.spill_cap * 2;
 	A.max_in_len = max_in_len;
 	A.sample_min = P.sample_min;
 	A.p = p;

@@ -123,6 +123,7 @@ def test_batch_api_rejects_bad_arguments_before_touching_the_device():
     ("CSNAPPY_HIP_S_ENTRIES", "0"), ("CSNAPPY_HIP_S_ENTRIES", "48"), ("CSNAPPY_HIP_S_ENTRIES", "8192"),
     ("CSNAPPY_HIP_DENSE_CAP", "0"), ("CSNAPPY_HIP_DENSE_CAP", "100"), ("CSNAPPY_HIP_DENSE_CAP", "99999"),
     ("CSNAPPY_HIP_WGS_PER_CU", "0"), ("CSNAPPY_HIP_WGS_PER_CU", "x"), ("CSNAPPY_HIP_TABLE", "nonsense"),
+    ("CSNAPPY_HIP_SPILL_CAP", "100"), ("CSNAPPY_HIP_SPILL_CAP", "16384"),
 ])
 def test_experiment_knobs_are_range_checked(name, value, monkeypatch):
     """The CSNAPPY_HIP_* environment knobs exist for experiments; a value outside its range makes

@@ -647,15 +647,24 @@ def test_cl_tester_round_trip_and_selftests(torch, urls, golden_dir, tmp_path):
     assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)
 
 
-PLACEMENTS = ["hash", "dense", "global", "dense-cap256"]
+PLACEMENTS = ["hash", "dense", "global", "dense-cap256", "dense-cap1024-spill6144", "dense-nospill"]
 
 
 def _force_placement(monkeypatch, placement):
     """hash / dense / global: where the parser keeps its table.  dense-cap256: a dense LDS table so
-    small that most fragments overflow it and take the second (global-table) launch."""
+    small that most buckets of a fragment live in its HBM spill-over, and fragments with more than
+    256 + 2048 buckets take the global-table launch.  dense-cap1024-spill6144: every full fragment
+    spills.  dense-nospill: no spill-over, the second launch with the larger LDS table instead."""
     if placement == "dense-cap256":
         monkeypatch.setenv("CSNAPPY_HIP_TABLE", "dense")
         monkeypatch.setenv("CSNAPPY_HIP_DENSE_CAP", "256")
+    elif placement == "dense-cap1024-spill6144":
+        monkeypatch.setenv("CSNAPPY_HIP_TABLE", "dense")
+        monkeypatch.setenv("CSNAPPY_HIP_DENSE_CAP", "1024")
+        monkeypatch.setenv("CSNAPPY_HIP_SPILL_CAP", "6144")
+    elif placement == "dense-nospill":
+        monkeypatch.setenv("CSNAPPY_HIP_TABLE", "dense")
+        monkeypatch.setenv("CSNAPPY_HIP_SPILL_CAP", "0")
     else:
         monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
 
