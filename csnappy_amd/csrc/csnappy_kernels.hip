@@ -265,10 +265,21 @@ DEVINL uint2 pack_record(uint32_t lit_start, uint32_t base, uint32_t cnd, uint32
 	return make_uint2(base | (cnd << 16), clen | (lit_start << 16));
 }
 
-template <bool PROF, int TAB>
-__device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
+/* PART: 0 = the whole fragment; 1 = the dense placement's prologue only (*nb_out = its bucket
+ * count, or kNoRecords when the fragment was handed to a later launch or needs no parsing here);
+ * 2 = everything behind the prologue.  The dense kernel runs part 1 and then part 2 in the
+ * instantiation that fits the fragment -- with or without the spill-over -- so that the usual
+ * fragment does not pay for the spill-over's selects (1-2 % of its time, measured). */
+enum { PART_ALL = 0, PART_PROLOGUE = 1, PART_PARSE = 2 };
+
+template <bool PROF, int TAB, bool SPILL = false, int PART = PART_ALL>
+__device__ __forceinline__ void parse_fragment_body(const CompressArgs &A, uint32_t *nb_out = nullptr)
 {
 	constexpr bool GTAB = TAB == TAB_GLOBAL, DENSE = TAB == TAB_LDS_DENSE;
+	static_assert(!SPILL || DENSE, "the spill-over belongs to the dense table");
+	static_assert(PART == PART_ALL || DENSE, "only the dense placement has a prologue to split off");
+	if (PART == PART_PROLOGUE)
+		*nb_out = kNoRecords;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t c = blockIdx.x; /* fragment of this chunk */
@@ -310,15 +321,20 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 	if (PROF)
 		t_begin = __builtin_amdgcn_s_memtime();
 
-	/* TAB_LDS_DENSE: buckets dense_cap.. of this fragment live in a small table in HBM (behind its
-	 * ids).  Fragments just over the LDS table's size -- URL lists sit at 4.3-5.5 k buckets -- are
-	 * then parsed in the same launch, their few high buckets costing a global gather per step,
-	 * instead of all over again with a larger LDS table and fewer fragments per CU. */
-	bool has_spill = false;
+	/* SPILL: buckets dense_cap.. of the fragment live in a small table in HBM behind its ids.
+	 * Fragments just over the LDS table's size -- URL lists sit at 4.3-5.5 k buckets -- are parsed
+	 * in the same launch with the same LDS geometry (14 per CU) this way, their few high buckets
+	 * costing a global gather per step, instead of all over again in a second launch with a larger
+	 * LDS table and 10 fragments per CU.  (Compiled into every fragment's parser, the selects cost
+	 * 1-2 % on text and 2-5 % on pages: the dense kernel holds both parsers and picks per fragment.) */
 	uint16_t *spill = reinterpret_cast<uint16_t *>(region + A.spill_off);
 
+	if (PART == PART_PROLOGUE && n < kMargin) {
+		*nb_out = 0; /* no prologue, no spill-over: part 2 writes the one literal */
+		return;
+	}
 	if (n >= kMargin) {
-		if (DENSE) {
+		if (DENSE && PART != PART_PARSE) {
 			/* ---- prologue: dense bucket ids (see the header comment) ----
 			 * seen1/seen2: slot hit at least once / at least twice; pref: buckets below a word */
 			const uint32_t nwords = (1u << (ws - 1)) >> 5; /* >= 8 */
@@ -426,13 +442,12 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			}
 			uint32_t nb;
 			uint32_t run = wave_excl_scan(mine, lane, &nb);
-			if (nb > A.dense_cap + A.spill_cap) {
-				/* more buckets than the LDS table and its spill-over hold: a later launch takes it */
+			if (nb > A.dense_cap + ((SPILL || PART == PART_PROLOGUE) ? A.spill_cap : 0u)) {
+				/* more buckets than the LDS table (and its spill-over) hold: a later launch takes it */
 				if (lane == 0)
 					A.rec_cnt[c] = kNoRecords;
 				return;
 			}
-			has_spill = nb > A.dense_cap;
 			for (uint32_t k = 0; k < per; ++k) {
 				const uint32_t w = lane * per + k;
 				if (w < nwords) {
@@ -464,7 +479,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 							wids[i + k] = (uint16_t)id[k];
 				}
 			});
-			if (has_spill) {
+			if (SPILL || (PART == PART_PROLOGUE && nb > A.dense_cap)) {
 				uint4 *z = reinterpret_cast<uint4 *>(spill);
 				for (uint32_t k = lane; k < (A.spill_cap * 2 + 15) / 16; k += 64)
 					z[k] = make_uint4(0, 0, 0, 0);
@@ -478,6 +493,10 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (PROF)
 				tp4 = __builtin_amdgcn_s_memtime();
+			if (PART == PART_PROLOGUE) {
+				*nb_out = nb;
+				return;
+			}
 		}
 		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
 		{
@@ -622,14 +641,14 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
 			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
 			uint32_t cand = 0, first_same;
-			/* (dense) my bucket is one of the few beyond the LDS table */
-			const bool spilled = DENSE && tabbed && slot >= A.dense_cap;
+			/* (SPILL) my bucket is one of the few beyond the LDS table */
+			const bool spilled = SPILL && tabbed && slot >= A.dense_cap;
 			if (!GTAB) {
 				const bool in_lds = tabbed && !spilled;
 				cand = tab[in_lds ? slot : 0u];
 				cand = in_lds ? cand : 0u;
 			}
-			if (DENSE && has_spill && ballot64(spilled)) {
+			if (SPILL && ballot64(spilled)) {
 				const uint32_t g = spill[spilled ? slot - A.dense_cap : 0u];
 				cand = spilled ? g : cand;
 			}
@@ -981,7 +1000,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A)
 				if (GTAB)
 					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
 			}
-			if (DENSE && has_spill && commit && spilled)
+			if (SPILL && commit && spilled)
 				spill[slot - A.dense_cap] = (uint16_t)(pos_c | (chk << 15));
 			wave_lds_fence();
 			if (PROF)
@@ -1033,6 +1052,21 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments(Compr
 /* table indexed by dense bucket ids, in LDS (the default for tables that would not fit) */
 extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense(CompressArgs A)
 {
+	uint32_t nb;
+	parse_fragment_body<false, TAB_LDS_DENSE, false, PART_PROLOGUE>(A, &nb);
+	if (nb == kNoRecords)
+		return;
+	/* a few buckets more than the LDS table holds: those few live in HBM (URL lists) */
+	if (nb > A.dense_cap)
+		parse_fragment_body<false, TAB_LDS_DENSE, true, PART_PARSE>(A);
+	else
+		parse_fragment_body<false, TAB_LDS_DENSE, false, PART_PARSE>(A);
+}
+
+/* ... without a spill-over (pages: the second launch's table holds any page, and re-reading the
+ * descriptors between the two parts is 2.5 % of a page's time) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_whole(CompressArgs A)
+{
 	parse_fragment_body<false, TAB_LDS_DENSE>(A);
 }
 
@@ -1056,6 +1090,11 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense
 extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_prof(CompressArgs A)
 {
 	parse_fragment_body<true, TAB_GLOBAL>(A);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_spill_prof(CompressArgs A)
+{
+	parse_fragment_body<true, TAB_LDS_DENSE, true>(A);
 }
 
 /* ==========================================================================================
@@ -2792,8 +2831,15 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		{ reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
 		  reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof) },
 	};
-	const void *k1 = kfns[P.tab][g_prof_buf ? 1 : 0];
+	const void *k1 = (P.tab == TAB_LDS_DENSE && !P.spill_cap && !g_prof_buf)
+				 ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_whole)
+				 : kfns[P.tab][g_prof_buf ? 1 : 0];
 	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
+	const void *ks = reinterpret_cast<const void *>(snappy_parse_fragments_dense_spill_prof);
+	if (P.spill_cap && g_prof_buf &&
+	    !hip_ok(hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
+		    "hipFuncSetAttribute"))
+		return CSNAPPY_HIP_E_RUNTIME;
 	if (!hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
 		    "hipFuncSetAttribute") ||
 	    (P.fallback &&
@@ -2818,6 +2864,16 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
 			    "launch snappy_parse_fragments"))
 			return CSNAPPY_HIP_E_RUNTIME;
+		if (P.spill_cap && g_prof_buf) {
+			/* (the profiling build of the dense kernel has no spill-over inside: what overflowed
+			 * its LDS table by a little runs here, same geometry, the overflow in HBM) */
+			A.sample_min = 0;
+			A.only_unparsed = 1;
+			if (!hip_ok(hipLaunchKernel(ks, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
+				    "launch snappy_parse_fragments_dense_spill"))
+				return CSNAPPY_HIP_E_RUNTIME;
+			A.sample_min = P.sample_min;
+		}
 		if (P.cap2) {
 			A.lds0 = P.lds0_2;
 			A.s_entries = P.s_entries_2;
