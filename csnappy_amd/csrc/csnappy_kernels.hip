@@ -2481,7 +2481,11 @@ struct Timer {
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
-constexpr uint32_t kDenseCapDefault = 5120; /* entries of the dense LDS table (10 KiB; 14 fragments per CU) */
+/* entries of the dense LDS table: 9 KiB + 1 KiB of filters = eight of gfx950's 1 280-byte LDS
+ * granules, 16 fragments per CU (5 120 entries need nine: 14 per CU).  Fragments with more buckets
+ * -- a quarter of G_text's, by a few dozen; most of urls.10K's, by a few hundred -- keep the rest
+ * in their HBM spill-over. */
+constexpr uint32_t kDenseCapDefault = 4608;
 constexpr uint32_t kDenseCap2 = 7168;       /* ... of the second dense launch (14 KiB; 10 per CU) */
 constexpr uint32_t kSpillCapDefault = 2048; /* buckets beyond the LDS table kept in HBM (4 KiB per fragment) */
 constexpr uint32_t kSampleMinDefault = 700; /* of 2048 sampled positions (text: ~1400, runs: ~300) */
@@ -2592,6 +2596,7 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	const uint32_t s_cap_hash = kn.s_entries ? kn.s_entries : 256u; /* (4 KiB pages: slot sharing is the rule) */
 	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
 	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
+	uint32_t dense_scratch = 0;
 	const uint32_t most = ((maxfrag / 2 + 63) & ~63u) + 64;
 	if (!kn.dense_cap && cap > most)
 		cap = most;
@@ -2628,9 +2633,11 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 			cap = ((most * 9 / 16) + 63) & ~63u;
 		}
 		P.dense_cap = cap;
-		const uint32_t scratch = 10u * (slots >> 5); /* prologue: two bitmaps + the prefix */
-		P.lds0 = 2 * cap > scratch ? 2 * cap : scratch;
-		P.lds0 = (P.lds0 + 15) & ~15u;
+		/* prologue: two bitmaps + the prefix.  The filters behind the table are set up after the
+		 * prologue, so they may lie inside its scratch. */
+		const uint32_t scratch = 10u * (slots >> 5);
+		dense_scratch = scratch;
+		P.lds0 = (2 * cap + 15) & ~15u;
 		filter_geometry(cap, s_cap, true, &P.s_entries, &P.s_shift);
 		P.fallback = (maxfrag > 3 && cap < (maxfrag - 3) / 2) || (kn.sample_min && maxfrag == kFragment);
 		P.sample_min = kn.sample_min;
@@ -2647,9 +2654,11 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 			P.cap2 = kDenseCap2;
 		}
 		if (P.cap2) {
-			P.lds0_2 = 2 * P.cap2 > scratch ? 2 * P.cap2 : scratch;
+			P.lds0_2 = (2 * P.cap2 + 15) & ~15u;
 			filter_geometry(P.cap2, s_cap, true, &P.s_entries_2, &P.s_shift_2);
 			P.lds_bytes_2 = P.lds0_2 + P.s_entries_2 * 4 * (P.s_shift_2 ? 2 : 1);
+			if (P.lds_bytes_2 < scratch)
+				P.lds_bytes_2 = scratch;
 		}
 	}
 	/* global-table geometry (first launch when forced, else the fallback) */
@@ -2668,6 +2677,8 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		P.s_shift = P.g_s_shift;
 	}
 	P.lds_bytes = P.lds0 + P.s_entries * 4 * (P.s_shift ? 2 : 1);
+	if (P.tab == TAB_LDS_DENSE && P.lds_bytes < dense_scratch)
+		P.lds_bytes = dense_scratch;
 	if (kn.wgs_per_cu) {
 		/* experiments: cap the fragments per CU by padding the LDS request */
 		const uint32_t pad = (kLdsPerCu / kn.wgs_per_cu) & ~255u;
