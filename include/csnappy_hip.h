@@ -46,7 +46,7 @@ const char *csnappy_hip_last_error(void);
  * all <= max_in_len: per 32 KiB fragment the parser's 8-byte (literal, copy) records (one per four
  * input bytes at most), the 2-byte bucket ids of its positions (or its global-memory hash table),
  * 4 KiB for the table entries of buckets beyond the LDS table, and a record count.  A batch is processed in chunks of 32768 fragments, so the size stops
- * growing there (about 6 GiB for 64 KiB blocks).  256-byte aligned base required.
+ * growing there (4.1 GiB for 64 KiB blocks, 0.5 GiB for 4 KiB pages).  256-byte aligned base required.
  */
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len);
 
