@@ -223,10 +223,11 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  * LDS has one uint16 entry per such bucket (~4.6 k on URL-like text, ~1 k on runs) and is indexed
  * by the id, which the lanes load with their 16 input bytes.  Same slots, same contents, same
  * order of updates as the reference's table -- only the slots nobody can ever read are gone.
- * Fragments with more buckets than the LDS carve holds are handed to a second launch that keeps
- * the full 2^p-byte table in global memory (TAB_GLOBAL); tables of <= 8 KiB are simply indexed
- * by the hash (TAB_LDS_HASH, no prologue).  The window is never staged: the input is read where
- * it lies.
+ * The LDS table has 4 608 entries (9 KiB + 1 KiB of filters = 16 fragments per CU); a fragment
+ * with up to 2 048 buckets more keeps those in a small table in HBM behind its ids (SPILL), and
+ * one with still more is handed to a second launch that keeps the full 2^p-byte table in global
+ * memory (TAB_GLOBAL); tables of <= 8 KiB are simply indexed by the hash (TAB_LDS_HASH, no
+ * prologue).  The window is never staged: the input is read where it lies.
  *
  * Step logic (restated lane by lane in tests/wave_model.py::compress_fragment_v4 and fuzzed
  * against the CPU checker):
@@ -323,7 +324,7 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A, uint3
 
 	/* SPILL: buckets dense_cap.. of the fragment live in a small table in HBM behind its ids.
 	 * Fragments just over the LDS table's size -- URL lists sit at 4.3-5.5 k buckets -- are parsed
-	 * in the same launch with the same LDS geometry (14 per CU) this way, their few high buckets
+	 * in the same launch with the same LDS geometry (16 per CU) this way, their few high buckets
 	 * costing a global gather per step, instead of all over again in a second launch with a larger
 	 * LDS table and 10 fragments per CU.  (Compiled into every fragment's parser, the selects cost
 	 * 1-2 % on text and 2-5 % on pages: the dense kernel holds both parsers and picks per fragment.) */
