@@ -1077,6 +1077,645 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(
 	parse_fragment_body<false, TAB_GLOBAL>(A);
 }
 
+/* ==========================================================================================
+ * The lean parser (round 3).  Same step logic as parse_fragment_body above -- dense and sparse
+ * steps, flagged lanes, wave-wide extension -- written for the scalar unit: one CU has ONE scalar
+ * ALU for its 16 resident parser waves and the round-2 loop spent 230 scalar instructions per
+ * 64-position step there (profiles/r03a_text_p16_instmix.txt), more than the vector units'
+ * share.  What changed:
+ *   - one cursor form.  The state between steps is (s, q1): the scan that starts at position s
+ *     has made q1 - 1 probes; q1 == 0 says "a copy just ended at ip = s - 1: insert ip - 1,
+ *     probe ip" (csnappy_compress.c:585-594), and that re-match probe is simply scan index -1
+ *     (33 stride-1 probes follow a copy, 32 the start of the fragment, :535-552).  Lane 0 of a
+ *     dense step is ALWAYS an insert-only lane -- ip - 1 after a copy, otherwise the last position
+ *     the previous step probed, whose re-insertion changes nothing -- so the spec = 0/1/2 cases
+ *     and their joins are gone.
+ *   - ulim (lanes in front of the scan limit) is arithmetic, not a ballot.
+ *   - the chain loop has one exit code; the last copy and the window it leaves are derived from
+ *     the `taken` mask after the walk instead of being tracked through it; a wide match that
+ *     leaves the step is a link of the chain like any other (its own lane writes its record).
+ *   - a visit of a flagged lane tests for a real slot-sharer first (one readlane, one compare);
+ *     the insert mask is only built when there is one.
+ *   - block descriptors are read once, before the prologue's stores, so they stay scalar loads.
+ * ======================================================================================== */
+struct Frag {
+	const uint8_t *src; /* the fragment's input */
+	uint8_t *region;    /* its `tabs` workspace region: dense ids (+ spill-over table) */
+	uint2 *R;           /* its records */
+	uint32_t n;         /* its bytes */
+	uint32_t shift;     /* 33 - table power */
+	uint32_t ws;
+	uint32_t c;         /* its index in the chunk */
+};
+
+DEVINL uint64_t uni64(uint64_t v)
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+	       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+
+/* false: nothing to parse here (no such fragment, block longer than promised, already parsed) */
+DEVINL bool frag_setup(const CompressArgs &A, Frag &F, bool gtab)
+{
+	const uint32_t c = blockIdx.x;
+	const uint32_t blk = A.blk_base + c / A.fpb, fi = c % A.fpb;
+	const uint32_t len = A.in_len[blk];
+	const uint32_t foff = fi * kFragment;
+	if ((fi > 0 && foff >= len) || len > A.max_in_len)
+		return false;
+	if (A.only_unparsed) {
+		const uint32_t state = A.rec_cnt[c];
+		if (state != kNoRecords && !(gtab && state == kWantGlobal))
+			return false;
+	}
+	F.c = c;
+	F.n = min(len - foff, kFragment);
+	F.ws = (uint32_t)fragment_power(F.n, A.p, A.mode);
+	F.shift = 33 - F.ws;
+	/* (pointers stay derived from the kernel arguments: laundering them through integers would
+	 * turn every access into a flat load, which also counts on the LDS counter) */
+	F.src = A.in + uni64(A.in_off[blk] + foff);
+	F.R = reinterpret_cast<uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
+	F.region = A.tabs + (uint64_t)c * A.tab_stride;
+	return true;
+}
+
+/* The dense placement's prologue (see parse_fragment_body): numbers the hash slots that two or
+ * more positions of the fragment hit and writes every position's dense bucket id to the fragment's
+ * workspace region.  Returns the bucket count, or kNoRecords when the fragment was handed to a
+ * later launch (too many buckets, or repetitive: the global-table launch is faster for it). */
+DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t n = F.n, shift = F.shift;
+	const uint8_t *src = F.src;
+	if (n < kMargin)
+		return 0;
+	const uint32_t nwords = (1u << (F.ws - 1)) >> 5; /* >= 8 */
+	uint32_t *seen1 = reinterpret_cast<uint32_t *>(smem), *seen2 = seen1 + nwords;
+	if (A.sample_min && n == kFragment) {
+		for (uint32_t k = lane; k < 256; k += 64)
+			seen1[k] = 0;
+		wave_lds_fence();
+		for (uint32_t j = 0; j < 32; ++j) {
+			uint32_t w;
+			__builtin_memcpy(&w, src + 16 * lane + 1024 * j, 4);
+			const uint32_t h = (w * kHashMul) >> 19;
+			atomicOr(&seen1[h >> 5], 1u << (h & 31));
+		}
+		wave_lds_fence();
+		uint32_t d = 0, distinct;
+		for (uint32_t k = 0; k < 4; ++k)
+			d += (uint32_t)__builtin_popcount(seen1[lane * 4 + k]);
+		(void)wave_excl_scan(d, lane, &distinct);
+		wave_lds_fence();
+		if (distinct < A.sample_min) {
+			if (lane == 0)
+				A.rec_cnt[F.c] = kWantGlobal;
+			return kNoRecords;
+		}
+	}
+	uint16_t *pref = reinterpret_cast<uint16_t *>(seen2 + nwords);
+	for (uint32_t k = lane; k < 2 * nwords; k += 64)
+		seen1[k] = 0;
+	wave_lds_fence();
+	const uint32_t npos = n - 3; /* positions that have four bytes */
+	auto load16 = [&](uint32_t i) -> uint4 {
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (i + 16 <= n) {
+			__builtin_memcpy(&v, src + i, 16);
+		} else if (i < n) {
+			uint32_t w[4] = { 0, 0, 0, 0 };
+			for (uint32_t k = 0; i + k < n; ++k)
+				w[k >> 2] |= (uint32_t)src[i + k] << (8 * (k & 3));
+			v = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+		return v;
+	};
+	auto hash8 = [&](const uint4 &v, uint32_t hh[8]) {
+		const uint32_t w0 = v.x, w1 = v.y, w2 = v.z;
+		hh[0] = (w0 * kHashMul) >> shift;
+		hh[1] = (__builtin_amdgcn_alignbyte(w1, w0, 1) * kHashMul) >> shift;
+		hh[2] = (__builtin_amdgcn_alignbyte(w1, w0, 2) * kHashMul) >> shift;
+		hh[3] = (__builtin_amdgcn_alignbyte(w1, w0, 3) * kHashMul) >> shift;
+		hh[4] = (w1 * kHashMul) >> shift;
+		hh[5] = (__builtin_amdgcn_alignbyte(w2, w1, 1) * kHashMul) >> shift;
+		hh[6] = (__builtin_amdgcn_alignbyte(w2, w1, 2) * kHashMul) >> shift;
+		hh[7] = (__builtin_amdgcn_alignbyte(w2, w1, 3) * kHashMul) >> shift;
+	};
+	auto sweep = [&](auto &&body) {
+		uint4 nxt[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j)
+			nxt[j] = load16(512 * j + 8 * lane);
+		for (uint32_t b0 = 0; b0 < npos; b0 += 2048) {
+			uint4 cur[4];
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				cur[j] = nxt[j];
+				if (b0 + 2048 < npos)
+					nxt[j] = load16(b0 + 2048 + 512 * j + 8 * lane);
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				const uint32_t i = b0 + 512 * j + 8 * lane;
+				if (b0 + 512 * j < npos)
+					body(cur[j], i, i < npos ? min(8u, npos - i) : 0u);
+			}
+		}
+	};
+	sweep([&](const uint4 &v, uint32_t, uint32_t cntp) {
+		uint32_t hh[8], old[8];
+		hash8(v, hh);
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k)
+			old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k)
+			if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
+				atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
+	});
+	wave_lds_fence();
+	const uint32_t per = max(1u, nwords >> 6);
+	uint32_t mine = 0;
+	for (uint32_t k = 0; k < per; ++k) {
+		const uint32_t w = lane * per + k;
+		if (w < nwords)
+			mine += (uint32_t)__builtin_popcount(seen2[w]);
+	}
+	uint32_t nb;
+	uint32_t run = wave_excl_scan(mine, lane, &nb);
+	if (nb > A.dense_cap + A.spill_cap) {
+		if (lane == 0)
+			A.rec_cnt[F.c] = kNoRecords;
+		return kNoRecords;
+	}
+	for (uint32_t k = 0; k < per; ++k) {
+		const uint32_t w = lane * per + k;
+		if (w < nwords) {
+			pref[w] = (uint16_t)run;
+			run += (uint32_t)__builtin_popcount(seen2[w]);
+		}
+	}
+	wave_lds_fence();
+	uint16_t *wids = reinterpret_cast<uint16_t *>(F.region);
+	sweep([&](const uint4 &v, uint32_t i, uint32_t cntp) {
+		uint32_t hh[8], id[8];
+		hash8(v, hh);
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) {
+			const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
+			const uint32_t b = 1u << (hh[k] & 31);
+			id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
+		}
+		if (cntp == 8) {
+			*reinterpret_cast<uint4 *>(wids + i) =
+				make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
+					   id[6] | (id[7] << 16));
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < 7; ++k)
+				if (k < cntp)
+					wids[i + k] = (uint16_t)id[k];
+		}
+	});
+	if (nb > A.dense_cap) {
+		uint4 *z = reinterpret_cast<uint4 *>(F.region + A.spill_off);
+		for (uint32_t k = lane; k < (A.spill_cap * 2 + 15) / 16; k += 64)
+			z[k] = make_uint4(0, 0, 0, 0);
+	}
+	wave_lds_fence();
+	/* the ids (and the zeroed spill table) are read back by this wave only (same CU, same L1/L2
+	 * path, program order); make the stores leave the wave before the first load of them */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	return nb;
+}
+
+template <int TAB, bool SPILL>
+DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
+{
+	constexpr bool DENSE = TAB == TAB_LDS_DENSE;
+	static_assert(TAB != TAB_GLOBAL, "the global-table placement keeps the round-2 loop");
+	static_assert(!SPILL || DENSE, "the spill-over belongs to the dense table");
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t n = F.n, shift = F.shift;
+	const uint8_t *src = F.src;
+	uint2 *R = F.R;
+	uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+	const uint16_t *ids = reinterpret_cast<const uint16_t *>(F.region);
+	uint16_t *spill = reinterpret_cast<uint16_t *>(F.region + A.spill_off);
+	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
+	uint32_t *S2 = S + A.s_entries;
+	const uint32_t smask = A.s_entries - 1;
+	const uint32_t s_shift = A.s_shift, dense_cap = A.dense_cap;
+	const bool two_filters = DENSE || s_shift != 0;
+
+	uint32_t nev = 0;       /* records written */
+	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
+	const uint64_t lt_mask = (1ull << lane) - 1;
+
+	if (n >= kMargin) {
+		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
+		const uint32_t zb = DENSE ? 2 * dense_cap : 1u << F.ws;
+		uint4 *z4 = reinterpret_cast<uint4 *>(smem);
+		for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
+			z4[k] = make_uint4(0, 0, 0, 0);
+		uint4 *s4 = reinterpret_cast<uint4 *>(S);
+		for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * A.s_entries) >> 2); k += 64)
+			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+		wave_lds_fence();
+	}
+
+	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
+	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
+		const uint32_t ma = cnd + kLocalMatch, mb = base + kLocalMatch, lim = n - mb;
+		uint32_t done = 0;
+		for (;;) {
+			const uint32_t o = done + lane * 8;
+			uint32_t m8 = 0;
+			bool term = true;
+			if (o < lim) {
+				/* the last few bytes of the fragment: never read past the input -- take the eight
+				 * bytes that END at the fragment's end and drop the ones in front of o */
+				const uint32_t r = min(8u, lim - o), back = 8 - r;
+				uint64_t xa, xb;
+				__builtin_memcpy(&xa, src + ma + o - back, 8);
+				__builtin_memcpy(&xb, src + mb + o - back, 8);
+				const uint64_t x = (xa ^ xb) >> (8 * back);
+				const uint32_t z = (uint32_t)__ffsll((unsigned long long)x); /* 0 when x == 0 */
+				m8 = z ? min((z - 1) >> 3, r) : r;
+				term = m8 < 8 || o + 8 >= lim;
+			}
+			const uint64_t tmask = ballot64(term);
+			if (tmask) {
+				const uint32_t t = first_lane(tmask);
+				return done + 8 * t + rdlane(m8, t);
+			}
+			done += 512;
+		}
+	};
+
+	/* (a 15-byte fragment has ip_limit 0: no probe ever happens, it is one literal like n < 15) */
+	if (n > kMargin) {
+		const uint32_t ip_limit = n - kMargin;
+		/* the cursor: scan start s, and q1 = 1 + index of the next scan probe; q1 == 0: the
+		 * re-match probe at s - 1 (a copy just ended there) comes first */
+		uint32_t s = 1, q1 = 1;
+		uint32_t epoch = 0x03ffffffu;
+		bool fin = false;
+		uint32_t first4;
+		__builtin_memcpy(&first4, src, 4);
+		const uint32_t chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
+
+		/* the lanes' 16 bytes and bucket ids are fetched one step ahead, as soon as the next
+		 * step's cursor is known */
+		uint32_t raw0, raw1, raw2, raw3, sid = kNoBucket;
+		uint32_t pos = 0;
+		bool valid = false;
+		auto place = [&]() {
+			if (q1 > 32) {
+				/* sparse: the next 64 probes of the stride rule; a probe happens only if the
+				 * NEXT position is still <= ip_limit (:542-544) */
+				pos = scan_pos(s, q1 - 1 + lane);
+				valid = scan_pos(s, q1 + lane) <= ip_limit;
+			} else {
+				pos = s + q1 - 2 + lane;
+				valid = pos < ip_limit;
+			}
+			pos = valid ? pos : 0u;
+			uint4 v;
+			__builtin_memcpy(&v, src + pos, 16);
+			const uint16_t idv = DENSE ? ids[pos] : (uint16_t)kNoBucket;
+			raw0 = v.x;
+			raw1 = v.y;
+			raw2 = v.z;
+			raw3 = v.w;
+			sid = idv;
+		};
+		place();
+
+		while (!fin) {
+			const bool sparse_c = q1 > 32;
+			const uint32_t p0 = s + q1 - 2; /* dense: position of lane 0 */
+			const uint32_t pos_c = pos;
+			const bool valid_c = valid;
+			const uint32_t me0 = raw0, me1 = raw1, me2 = raw2, me3 = raw3;
+			const uint32_t prod = me0 * kHashMul;
+			const uint32_t slot = DENSE ? sid : prod >> shift;
+			const bool tabbed = DENSE ? valid_c && slot != kNoBucket : valid_c;
+			const uint32_t chk = (prod >> (shift - 1)) & 1u;
+			const uint32_t key = slot & smask;
+			const uint32_t key2 = DENSE ? ((slot >> s_shift) ^ (slot << (s_shift - 5))) & smask
+						    : (slot >> s_shift) & smask;
+			const uint32_t ftag = tabbed ? (epoch << 6) | lane : ~0u;
+			atomicMin(&S[key], ftag);
+			if (two_filters)
+				atomicMin(&S2[key2], ftag);
+			uint32_t cand;
+			const bool spilled = SPILL && tabbed && slot >= dense_cap;
+			{
+				const bool in_lds = tabbed && !spilled;
+				cand = tab[in_lds ? slot : 0u];
+				cand = in_lds ? cand : 0u;
+			}
+			if (SPILL && ballot64(spilled)) {
+				const uint32_t g = spill[spilled ? slot - dense_cap : 0u];
+				cand = spilled ? g : cand;
+			}
+			wave_lds_fence();
+			uint32_t first_same = S[key] & 63u;
+			if (two_filters)
+				first_same = max(first_same, S2[key2] & 63u);
+			const bool flagged = tabbed && first_same < lane;
+			const uint64_t cmask = ballot64(flagged);
+			const uint64_t tmask = ballot64(tabbed);
+			epoch--;
+
+			uint32_t e_final;
+			bool inside = false;
+			uint2 rec = make_uint2(0, 0);
+			bool rec_mine = false;
+			uint32_t rec_idx = 0;
+
+			if (sparse_c) {
+				/* ---- sparse step: the lanes are the next probes of the stride rule; it ends at its
+				 * first match, and in front of the first lane that shares a slot with an earlier one */
+				const uint64_t imask = ~ballot64(valid_c);
+				const uint32_t c1 = cmask ? first_lane(cmask) : 64u;
+				const uint32_t v = imask ? first_lane(imask) : 64u;
+				const uint32_t ulim = min(c1, v);
+				const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk;
+				cand &= 0x7fffu;
+				const bool gathered = lane < ulim && maybe;
+				uint4 w4;
+				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
+				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
+				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
+				const uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
+				const uint64_t matchmask = ballot64(lane < ulim && mlen >= 4);
+				if (matchmask == 0) {
+					e_final = ulim - 1; /* (ulim == 0 cannot happen: lane 0 is never flagged, and an invalid lane 0 ended the scan before) */
+					if (ulim == v && v < 64)
+						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
+					else
+						q1 += ulim;
+				} else {
+					const uint32_t i = first_lane(matchmask);
+					e_final = i;
+					const uint32_t base = rdlane(pos_c, i), cnd = rdlane(cand, i);
+					uint32_t L = rdlane(mlen, i);
+					if (L == kLocalMatch && base + L < n)
+						L += extend(cnd, base);
+					if (lane == 0)
+						R[nev] = pack_record(next_emit, base, cnd, L);
+					++nev;
+					const uint32_t ip = base + L;
+					next_emit = ip;
+					if (ip >= ip_limit)
+						fin = true; /* :585-586 */
+					s = ip + 1;
+					q1 = 0;
+				}
+				if (!fin)
+					place();
+			} else {
+				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
+				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
+				const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
+				cand &= 0x7fffu;
+				uint4 w4;
+				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
+				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
+				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
+				uint32_t mlen = maybe ? common_prefix16(xlo, xhi) : 0u;
+				const uint64_t matchmask = ballot64(mlen >= 4) & ~1ull;
+				/* flagged lanes are stops of the chain like matches: what they hold is decided
+				 * when (and if) the chain gets there */
+				const uint64_t stopmask = matchmask | cmask;
+				const uint64_t special = ballot64(mlen == kLocalMatch && p0 + lane + kLocalMatch < n) | cmask;
+				uint32_t cl = lane + mlen; /* lane of the re-match probe after my match */
+				/* c = lane behind a copy: the next stop of the chain.  64: the re-match probe falls
+				 * outside the usable lanes; 65: none of the 33 probes behind the copy is a stop;
+				 * lane | 128: that stop is a special lane */
+				uint32_t nx;
+				{
+					const uint64_t rest = stopmask >> (cl & 63u);
+					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					const uint32_t j = cl + fm;
+					const bool in = fm <= 32 && j <= 63;
+					const uint32_t sp = (uint32_t)(special >> (j & 63u)) & 1u;
+					nx = cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
+				}
+				auto scalar_next = [&](uint32_t cc) -> uint32_t {
+					if (cc >= ulim)
+						return 64u;
+					const uint64_t rest = stopmask >> cc;
+					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					const uint32_t j = cc + fm;
+					if (fm > 32 || j > 63)
+						return 65u;
+					return j | (((uint32_t)(special >> j) & 1u) << 7);
+				};
+				/* the first segment: lanes 1 .. lim0 are what is left of the current scan's
+				 * stride-1 probes */
+				const uint32_t lim0 = 33 - q1;
+				uint32_t t;
+				{
+					const uint32_t i0 = stopmask ? first_lane(stopmask) : 64u;
+					t = (i0 <= lim0 && i0 <= 63) ? i0 | (((uint32_t)(special >> (i0 & 63u)) & 1u) << 7) : 65u;
+				}
+				uint64_t taken = 0; /* lanes whose match is part of the chain */
+				for (;;) {
+					/* plain matches: hop from match to match */
+					while (t < 64) {
+						const uint32_t i = t;
+						t = rdlane(nx, i);
+						asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */
+					}
+					if (t < 128)
+						break;
+					const uint32_t i = t & 63u;
+					uint32_t L = rdlane(mlen, i);
+					if ((cmask >> i) & 1) {
+						/* ---- the chain probes a flagged lane ----
+						 * Its candidate is the latest position inserted for its slot: the highest
+						 * lane below it that this step inserts (not strictly inside a copy of the
+						 * chain) and that has the same slot -- whose bytes are that lane's own 16
+						 * bytes -- else the table value it already compared with. */
+						const uint32_t slot_i = rdlane(slot, i);
+						uint64_t same = ballot64(slot == slot_i) & tmask & ((1ull << i) - 1);
+						if (same) {
+							const uint64_t below = taken & lt_mask;
+							const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+							const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+							same &= ~ballot64(below != 0 && lane + 1 < cprev);
+						}
+						if (same) {
+							const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
+							const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
+							const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
+							const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
+							const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
+							const uint32_t ml = common_prefix16(ylo, yhi);
+							L = rdlane(ml, i);
+							if (lane == i)
+								cand = p0 + j;
+						}
+						if (L < 4) {
+							/* no match: on to the next stop of the current window */
+							const uint32_t lim_cur = taken ? rdlane(cl, 63u - (uint32_t)__builtin_clzll(taken)) + 32 : lim0;
+							const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
+							const uint32_t i2 = m ? first_lane(m) : 64u;
+							t = (i2 > lim_cur || i2 > 63) ? 65u : i2 | (((uint32_t)(special >> (i2 & 63u)) & 1u) << 7);
+							continue;
+						}
+					}
+					if (L == kLocalMatch && p0 + i + kLocalMatch < n) {
+						/* longer than the lane-local cap: extend it wave-wide (it may leave the step) */
+						L = kLocalMatch + extend(rdlane(cand, i), p0 + i);
+					}
+					if (lane == i) {
+						mlen = L;
+						cl = lane + L;
+					}
+					taken |= 1ull << i;
+					t = scalar_next(i + L);
+				}
+				/* ---- where the chain left the step ---- */
+				const uint32_t emit0 = next_emit, nev0 = nev;
+				uint32_t c = 0, ip = 0;
+				if (taken) {
+					c = rdlane(cl, 63u - (uint32_t)__builtin_clzll(taken));
+					ip = p0 + c;
+					next_emit = ip;
+				}
+				if (t == 64) {
+					/* the last copy ends at or behind the usable lanes: re-match probe next (:585-594) */
+					e_final = 63u - (uint32_t)__builtin_clzll(taken);
+					s = ip + 1;
+					q1 = 0;
+					fin = ip >= ip_limit; /* :585-586 */
+				} else {
+					/* the current window (33 probes behind the last copy, or what was left of the scan
+					 * the step started in) has no match */
+					const uint32_t lim = taken ? c + 32 : lim0;
+					const uint32_t e = min(lim, ulim - 1);
+					e_final = e;
+					if (ulim <= lim && ulim < 64) {
+						fin = true; /* the next probe is past ip_limit: goto emit_remainder, :543-544 */
+					} else if (taken) {
+						s = ip + 1;
+						q1 = e + 1 - c;
+					} else {
+						q1 += e;
+					}
+				}
+				/* the cursor of the next step is known: fetch its bytes now */
+				if (!fin)
+					place();
+				/* ---- records of the taken matches, built by their own lanes ---- */
+				if (taken) {
+					const uint64_t below = taken & lt_mask;
+					const bool hasprev = below != 0;
+					const uint32_t jprev = hasprev ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+					rec_mine = (taken >> lane) & 1;
+					const uint32_t lit_start = hasprev ? p0 + cprev : emit0;
+					inside = hasprev && lane + 1 < cprev; /* strictly inside a taken copy: never inserted */
+					rec_idx = nev0 + (uint32_t)__builtin_popcountll(below);
+					rec = pack_record(lit_start, p0 + lane, cand, mlen);
+					nev = nev0 + (uint32_t)__builtin_popcountll(taken);
+				}
+			}
+			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
+			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
+			 * behind the stores would also sit out the stores' round trip. */
+			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
+			if (rec_mine)
+				R[rec_idx] = rec;
+			/* commit table[slot] = position for every lane that was probed or inserted
+			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
+			bool commit = lane <= e_final && !inside && tabbed;
+			{
+				/* of several committed lanes with one slot only the last may write */
+				const uint64_t cm = ballot64(commit);
+				uint64_t fl = cmask & cm;
+				if (fl) {
+					uint64_t dead = 0;
+					if (SPILL || __builtin_popcountll(fl) <= 6) {
+						do {
+							const uint32_t x = first_lane(fl);
+							fl &= fl - 1;
+							dead |= ballot64(slot == rdlane(slot, x)) & ((1ull << x) - 1);
+						} while (fl);
+					} else {
+						/* many sharers (runs): settle it through the table entries themselves.  Every
+						 * round the pending lanes that lost to a LOWER lane write their lane number
+						 * again; a lane that reads back a higher one is dead.  The winner of a slot
+						 * only ever moves up, so this ends with the highest lane of every slot. */
+						bool pend = commit, wr = commit;
+						for (;;) {
+							if (wr)
+								tab[slot] = (uint16_t)lane;
+							wave_lds_fence();
+							const uint32_t w = tab[pend ? slot : 0u];
+							wave_lds_fence();
+							dead |= ballot64(pend && lane < w);
+							pend = pend && lane >= w;
+							wr = pend && lane > w;
+							if (!ballot64(wr))
+								break;
+						}
+					}
+					if ((dead >> lane) & 1)
+						commit = false;
+				}
+			}
+			if (commit && !spilled)
+				tab[slot] = (uint16_t)(pos_c | (chk << 15));
+			if (SPILL && commit && spilled)
+				spill[slot - dense_cap] = (uint16_t)(pos_c | (chk << 15));
+			wave_lds_fence();
+		}
+	}
+
+	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
+	if (next_emit < n) {
+		if (lane == 0)
+			R[nev] = pack_record(next_emit, n, n, 0);
+		++nev;
+	}
+	if (lane == 0)
+		A.rec_cnt[F.c] = nev;
+}
+
+/* table indexed by dense bucket ids, in LDS: prologue, then the parser with or without the
+ * spill-over's selects */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_lean(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, false))
+		return;
+	const uint32_t nb = dense_prologue(A, F);
+	if (nb == kNoRecords)
+		return;
+	if (nb > A.dense_cap)
+		parse_lean<TAB_LDS_DENSE, true>(A, F);
+	else
+		parse_lean<TAB_LDS_DENSE, false>(A, F);
+}
+
+/* table indexed by the hash, in LDS (tables of <= 8 KiB) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_hash_lean(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, false))
+		return;
+	parse_lean<TAB_LDS_HASH, false>(A, F);
+}
+
 /* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
 extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_prof(CompressArgs A)
 {
@@ -2524,6 +3163,7 @@ struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
 	bool ok;
+	bool old_parser; /* CSNAPPY_HIP_PARSER=old: the round-2 step loop (A/B timing) */
 };
 
 bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
@@ -2541,7 +3181,9 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true };
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true, false };
+	if (const char *e = getenv("CSNAPPY_HIP_PARSER"))
+		k.old_parser = !strcmp(e, "old");
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -2846,6 +3488,12 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	const void *k1 = (P.tab == TAB_LDS_DENSE && !P.spill_cap && !g_prof_buf)
 				 ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_whole)
 				 : kfns[P.tab][g_prof_buf ? 1 : 0];
+	if (!g_prof_buf && !kn.old_parser) {
+		if (P.tab == TAB_LDS_DENSE)
+			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean);
+		else if (P.tab == TAB_LDS_HASH)
+			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean);
+	}
 	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
 	const void *ks = reinterpret_cast<const void *>(snappy_parse_fragments_dense_spill_prof);
 	if (P.spill_cap && g_prof_buf &&
