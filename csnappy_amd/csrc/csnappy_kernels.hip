@@ -1292,9 +1292,22 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	return nb;
 }
 
-template <int TAB, bool SPILL>
+template <int TAB, bool SPILL, bool PROF = false>
 DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 {
+	/* PROF: s_memtime phase counters (debug kernels only; tools/phase_lean.py) */
+	unsigned long long pt[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long pt_last = 0, pt_begin = 0, pn_steps = 0, pn_special = 0, pn_hops = 0, pn_sparse = 0;
+	unsigned long long pn_tabbed = 0, pn_gathered = 0, pn_match4 = 0, pn_flagged = 0;
+	auto tick = [&](int k) {
+		if (PROF) {
+			const unsigned long long now = __builtin_amdgcn_s_memtime();
+			pt[k] += now - pt_last;
+			pt_last = now;
+		}
+	};
+	if (PROF)
+		pt_begin = pt_last = __builtin_amdgcn_s_memtime();
 	constexpr bool DENSE = TAB == TAB_LDS_DENSE;
 	static_assert(TAB != TAB_GLOBAL, "the global-table placement keeps the round-2 loop");
 	static_assert(!SPILL || DENSE, "the spill-over belongs to the dense table");
@@ -1375,19 +1388,19 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t pos = 0;
 		bool valid = false;
 		auto place = [&]() {
+			pos = s + q1 - 2 + lane;
+			valid = pos < ip_limit;
 			if (q1 > 32) {
 				/* sparse: the next 64 probes of the stride rule; a probe happens only if the
 				 * NEXT position is still <= ip_limit (:542-544) */
 				pos = scan_pos(s, q1 - 1 + lane);
 				valid = scan_pos(s, q1 + lane) <= ip_limit;
-			} else {
-				pos = s + q1 - 2 + lane;
-				valid = pos < ip_limit;
 			}
 			pos = valid ? pos : 0u;
 			uint4 v;
 			__builtin_memcpy(&v, src + pos, 16);
-			const uint16_t idv = DENSE ? ids[pos] : (uint16_t)kNoBucket;
+			/* (the ids are read once: streaming hint, they should not push the window out of L2) */
+			const uint16_t idv = DENSE ? __builtin_nontemporal_load(ids + pos) : (uint16_t)kNoBucket;
 			raw0 = v.x;
 			raw1 = v.y;
 			raw2 = v.z;
@@ -1397,6 +1410,13 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		place();
 
 		while (!fin) {
+			tick(0); /* (rest of the previous step: commit) */
+			if (PROF) {
+				asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				pn_steps++;
+			}
+			tick(1); /* wait for the step's own bytes and ids */
 			const bool sparse_c = q1 > 32;
 			const uint32_t p0 = s + q1 - 2; /* dense: position of lane 0 */
 			const uint32_t pos_c = pos;
@@ -1425,6 +1445,15 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				cand = spilled ? g : cand;
 			}
 			wave_lds_fence();
+			/* the candidate's 16 bytes are requested as soon as the table entry is there, in front of
+			 * the filters' read-back (dense steps; lanes without a candidate read position 0 -- one
+			 * broadcast line, cheaper than masking the load off) */
+			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
+			cand &= 0x7fffu;
+			uint4 w4 = make_uint4(0, 0, 0, 0);
+			if (!sparse_c) {
+				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
+			}
 			uint32_t first_same = S[key] & 63u;
 			if (two_filters)
 				first_same = max(first_same, S2[key2] & 63u);
@@ -1432,6 +1461,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			const uint64_t cmask = ballot64(flagged);
 			const uint64_t tmask = ballot64(tabbed);
 			epoch--;
+			uint32_t touch_a = 0, touch_b = 0;
+			tick(2); /* filters + table */
 
 			uint32_t e_final;
 			bool inside = false;
@@ -1446,10 +1477,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t c1 = cmask ? first_lane(cmask) : 64u;
 				const uint32_t v = imask ? first_lane(imask) : 64u;
 				const uint32_t ulim = min(c1, v);
-				const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk;
-				cand &= 0x7fffu;
 				const bool gathered = lane < ulim && maybe;
-				uint4 w4;
 				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
@@ -1478,19 +1506,35 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					s = ip + 1;
 					q1 = 0;
 				}
-				if (!fin)
-					place();
+				place();
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
-				const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
-				cand &= 0x7fffu;
-				uint4 w4;
-				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
+				/* behind the gather (loads return in order: in front of it, the gather would wait for
+				 * these too): touch the input and id lines two steps ahead -- the exact cursor is not
+				 * known yet, the lines are -- so that the next place() finds them in the cache */
+				{
+					const uint32_t ta = min(p0 + 128 + 4 * lane, n - 4);
+					__builtin_memcpy(&touch_a, src + ta, 4);
+					if (DENSE)
+						touch_b = ids[min(p0 + 128 + 2 * lane, n - 1)];
+				}
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
+				if (PROF) {
+					asm volatile("" : "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				}
+				tick(3); /* candidate gather */
+				if (PROF) {
+					pn_tabbed += __builtin_popcountll(tmask);
+					pn_gathered += __builtin_popcountll(ballot64(maybe));
+					pn_flagged += __builtin_popcountll(cmask);
+				}
 				uint32_t mlen = maybe ? common_prefix16(xlo, xhi) : 0u;
 				const uint64_t matchmask = ballot64(mlen >= 4) & ~1ull;
+				if (PROF)
+					pn_match4 += __builtin_popcountll(matchmask);
 				/* flagged lanes are stops of the chain like matches: what they hold is decided
 				 * when (and if) the chain gets there */
 				const uint64_t stopmask = matchmask | cmask;
@@ -1527,6 +1571,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					t = (i0 <= lim0 && i0 <= 63) ? i0 | (((uint32_t)(special >> (i0 & 63u)) & 1u) << 7) : 65u;
 				}
 				uint64_t taken = 0; /* lanes whose match is part of the chain */
+				tick(4); /* match lengths, next-stop table */
 				for (;;) {
 					/* plain matches: hop from match to match */
 					while (t < 64) {
@@ -1538,6 +1583,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						break;
 					const uint32_t i = t & 63u;
 					uint32_t L = rdlane(mlen, i);
+					if (PROF)
+						pn_special++;
 					if ((cmask >> i) & 1) {
 						/* ---- the chain probes a flagged lane ----
 						 * Its candidate is the latest position inserted for its slot: the highest
@@ -1583,38 +1630,31 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					taken |= 1ull << i;
 					t = scalar_next(i + L);
 				}
-				/* ---- where the chain left the step ---- */
+				/* ---- where the chain left the step (selects, no branches: this is scalar code) ----
+				 * t == 64: the last copy ends at or behind the usable lanes: re-match probe next
+				 * (:585-594).  t == 65: the current window (the 33 probes behind the last copy, or what
+				 * was left of the scan the step started in) has no match: the scan goes on behind its
+				 * last probed lane e, or runs into the scan limit (goto emit_remainder, :543-544). */
+				tick(5); /* chain walk */
+				if (PROF)
+					pn_hops += __builtin_popcountll(taken);
 				const uint32_t emit0 = next_emit, nev0 = nev;
-				uint32_t c = 0, ip = 0;
-				if (taken) {
-					c = rdlane(cl, 63u - (uint32_t)__builtin_clzll(taken));
-					ip = p0 + c;
-					next_emit = ip;
-				}
-				if (t == 64) {
-					/* the last copy ends at or behind the usable lanes: re-match probe next (:585-594) */
-					e_final = 63u - (uint32_t)__builtin_clzll(taken);
-					s = ip + 1;
-					q1 = 0;
-					fin = ip >= ip_limit; /* :585-586 */
-				} else {
-					/* the current window (33 probes behind the last copy, or what was left of the scan
-					 * the step started in) has no match */
-					const uint32_t lim = taken ? c + 32 : lim0;
-					const uint32_t e = min(lim, ulim - 1);
-					e_final = e;
-					if (ulim <= lim && ulim < 64) {
-						fin = true; /* the next probe is past ip_limit: goto emit_remainder, :543-544 */
-					} else if (taken) {
-						s = ip + 1;
-						q1 = e + 1 - c;
-					} else {
-						q1 += e;
-					}
-				}
-				/* the cursor of the next step is known: fetch its bytes now */
-				if (!fin)
-					place();
+				const bool any = taken != 0;
+				const uint32_t last = 63u - (uint32_t)__builtin_clzll(taken | 1);
+				const uint32_t c = rdlane(cl, last); /* (no copy: lane 0's, unused) */
+				const uint32_t ip = p0 + c;
+				const bool end_a = t == 64;
+				const uint32_t lim = any ? c + 32 : lim0;
+				const uint32_t e = min(lim, ulim - 1);
+				e_final = end_a ? last : e;
+				fin = end_a ? ip >= ip_limit /* :585-586 */ : (ulim <= lim && ulim < 64);
+				next_emit = any ? ip : next_emit;
+				q1 = end_a ? 0u : any ? e + 1 - c : q1 + e;
+				s = any ? ip + 1 : s;
+				/* the cursor of the next step is known: fetch its bytes now (after the last step the
+				 * loads are harmless: an invalid lane reads position 0) */
+				place();
+				tick(6); /* cursor update, next step's loads issued */
 				/* ---- records of the taken matches, built by their own lanes ---- */
 				if (taken) {
 					const uint64_t below = taken & lt_mask;
@@ -1632,9 +1672,16 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
 			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
 			 * behind the stores would also sit out the stores' round trip. */
-			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
+			tick(7); /* records built */
+			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid) : "v"(touch_a), "v"(touch_b));
+			if (PROF)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
+			if (PROF && sparse_c)
+				pn_sparse++;
 			if (rec_mine)
-				R[rec_idx] = rec;
+				__builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&rec),
+							    reinterpret_cast<unsigned long long *>(R + rec_idx));
 			/* commit table[slot] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			bool commit = lane <= e_final && !inside && tabbed;
@@ -1689,6 +1736,21 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	}
 	if (lane == 0)
 		A.rec_cnt[F.c] = nev;
+	if (PROF && lane == 0) {
+		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+		atomicAdd(&A.prof[0], t_end - pt_begin);
+		for (int k = 0; k < 9; ++k)
+			atomicAdd(&A.prof[1 + k], pt[k]);
+		atomicAdd(&A.prof[10], pn_steps);
+		atomicAdd(&A.prof[11], pn_hops);
+		atomicAdd(&A.prof[12], pn_special);
+		atomicAdd(&A.prof[13], pn_sparse);
+		atomicAdd(&A.prof[14], 1ull);
+		atomicAdd(&A.prof[16], pn_tabbed);
+		atomicAdd(&A.prof[17], pn_gathered);
+		atomicAdd(&A.prof[18], pn_match4);
+		atomicAdd(&A.prof[19], pn_flagged);
+	}
 }
 
 /* table indexed by dense bucket ids, in LDS: prologue, then the parser with or without the
@@ -1714,6 +1776,24 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_hash_
 	if (!frag_setup(A, F, false))
 		return;
 	parse_lean<TAB_LDS_HASH, false>(A, F);
+}
+
+/* debug: the dense kernel with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_lean_prof(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, false))
+		return;
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	const uint32_t nb = dense_prologue(A, F);
+	if (nb == kNoRecords)
+		return;
+	if (threadIdx.x == 0)
+		atomicAdd(&A.prof[15], __builtin_amdgcn_s_memtime() - t0);
+	if (nb > A.dense_cap)
+		parse_lean<TAB_LDS_DENSE, true, true>(A, F);
+	else
+		parse_lean<TAB_LDS_DENSE, false, true>(A, F);
 }
 
 /* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
@@ -3488,12 +3568,15 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	const void *k1 = (P.tab == TAB_LDS_DENSE && !P.spill_cap && !g_prof_buf)
 				 ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_whole)
 				 : kfns[P.tab][g_prof_buf ? 1 : 0];
+	const bool lean_prof = g_prof_buf && !kn.old_parser && P.tab == TAB_LDS_DENSE;
 	if (!g_prof_buf && !kn.old_parser) {
 		if (P.tab == TAB_LDS_DENSE)
 			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean);
 		else if (P.tab == TAB_LDS_HASH)
 			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean);
 	}
+	if (lean_prof)
+		k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof);
 	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
 	const void *ks = reinterpret_cast<const void *>(snappy_parse_fragments_dense_spill_prof);
 	if (P.spill_cap && g_prof_buf &&
@@ -3524,7 +3607,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
 			    "launch snappy_parse_fragments"))
 			return CSNAPPY_HIP_E_RUNTIME;
-		if (P.spill_cap && g_prof_buf) {
+		if (P.spill_cap && g_prof_buf && !lean_prof) {
 			/* (the profiling build of the dense kernel has no spill-over inside: what overflowed
 			 * its LDS table by a little runs here, same geometry, the overflow in HBM) */
 			A.sample_min = 0;
