@@ -1499,7 +1499,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				wave_lds_fence();
 				epoch = kFilterEpochs;
 			}
-			uint32_t touch_a = 0, touch_b = 0;
 			tick(2); /* filters + table */
 
 			uint32_t e_final;
@@ -1548,15 +1547,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
-				/* behind the gather (loads return in order: in front of it, the gather would wait for
-				 * these too): touch the input and id lines two steps ahead -- the exact cursor is not
-				 * known yet, the lines are -- so that the next place() finds them in the cache */
-				{
-					const uint32_t ta = min(p0 + 128 + 4 * lane, n - 4);
-					__builtin_memcpy(&touch_a, src + ta, 4);
-					if (DENSE)
-						touch_b = ids[min(p0 + 128 + 2 * lane, n - 1)];
-				}
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
 				if (PROF) {
@@ -1711,7 +1701,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
 			 * behind the stores would also sit out the stores' round trip. */
 			tick(7); /* records built */
-			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid) : "v"(touch_a), "v"(touch_b));
+			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
 			if (PROF)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
@@ -1833,595 +1823,6 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense
 		parse_lean<TAB_LDS_DENSE, true, true>(A, F);
 	else
 		parse_lean<TAB_LDS_DENSE, false, true>(A, F);
-}
-
-/* ==========================================================================================
- * The wide parser: dense steps of 128 positions, two per lane.
- *
- * One fragment is one dependent chain of steps, and a lone wave needs ~3 800 cycles for a
- * 64-position step however few instructions that is: two LDS round trips, the candidate gather,
- * the chain walk's readlane/branch latencies, the cursor update.  Sixteen waves per CU hide part
- * of it (tools/phase_lean.py, occupancy sweep in DESIGN.md); the rest is paid per STEP.  So the
- * step is made twice as wide: lane L holds positions p0 + L ("half 0") and p0 + 64 + L
- * ("half 1"), the vector work of both halves is issued together (one wait for the table
- * entries, one for the gather, one for the next step's bytes), and one chain walk runs through
- * the 128 "virtual lanes" v = 64 h + L.  Everything else is parse_lean's logic with 128-bit stop
- * masks: flagged lanes (a slot shared with any lower virtual lane), forwarding from the registers
- * of either half, one cursor update and one commit per 128 positions.  v_readlane and s_bitset
- * take their lane from the low six bits of the index, so the hop loops need no arithmetic on the
- * virtual lane number.  Sparse steps (stride-2.. scans, :542) stay 64 probes wide in half 0.
- * ======================================================================================== */
-template <bool SPILL, bool PROF = false>
-DEVINL void parse_wide(const CompressArgs &A, const Frag &F)
-{
-	/* PROF: s_memtime phase counters (debug kernels only; tools/phase_lean.py) */
-	unsigned long long pt[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	unsigned long long pt_last = 0, pt_begin = 0, pn_steps = 0, pn_special = 0, pn_hops = 0, pn_sparse = 0;
-	unsigned long long pn_tabbed = 0, pn_gathered = 0, pn_match4 = 0, pn_flagged = 0;
-	auto tick = [&](int k) {
-		if (PROF) {
-			const unsigned long long now = __builtin_amdgcn_s_memtime();
-			pt[k] += now - pt_last;
-			pt_last = now;
-		}
-	};
-	if (PROF)
-		pt_begin = pt_last = __builtin_amdgcn_s_memtime();
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const uint32_t lane = threadIdx.x;
-	const uint32_t n = F.n, shift = F.shift;
-	const uint8_t *src = F.src;
-	uint2 *R = F.R;
-	uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
-	const uint16_t *ids = reinterpret_cast<const uint16_t *>(F.region);
-	uint16_t *spill = reinterpret_cast<uint16_t *>(F.region + A.spill_off);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
-	uint32_t *S2 = S + A.s_entries;
-	const uint32_t smask = A.s_entries - 1;
-	const uint32_t s_shift = A.s_shift, dense_cap = A.dense_cap;
-
-	uint32_t nev = 0;       /* records written */
-	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
-	const uint64_t lt_mask = (1ull << lane) - 1;
-	bool stuck = false;
-
-	if (n >= kMargin) {
-		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
-		const uint32_t zb = 2 * dense_cap;
-		uint4 *z4 = reinterpret_cast<uint4 *>(smem);
-		for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
-			z4[k] = make_uint4(0, 0, 0, 0);
-		uint4 *s4 = reinterpret_cast<uint4 *>(S);
-		for (uint32_t k = lane; k < ((2 * A.s_entries) >> 2); k += 64)
-			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-		wave_lds_fence();
-	}
-
-	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
-	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
-		const uint32_t ma = cnd + kLocalMatch, mb = base + kLocalMatch, lim = n - mb;
-		uint32_t done = 0;
-		for (;;) {
-			const uint32_t o = done + lane * 8;
-			uint32_t m8 = 0;
-			bool term = true;
-			if (o < lim) {
-				const uint32_t r = min(8u, lim - o), back = 8 - r;
-				uint64_t xa, xb;
-				__builtin_memcpy(&xa, src + ma + o - back, 8);
-				__builtin_memcpy(&xb, src + mb + o - back, 8);
-				const uint64_t x = (xa ^ xb) >> (8 * back);
-				const uint32_t z = (uint32_t)__ffsll((unsigned long long)x); /* 0 when x == 0 */
-				m8 = z ? min((z - 1) >> 3, r) : r;
-				term = m8 < 8 || o + 8 >= lim;
-			}
-			const uint64_t tmask = ballot64(term);
-			if (tmask) {
-				const uint32_t t = first_lane(tmask);
-				return done + 8 * t + rdlane(m8, t);
-			}
-			done += 512;
-		}
-	};
-
-	if (n > kMargin) {
-		const uint32_t ip_limit = n - kMargin;
-		/* the cursor (see parse_lean): scan start s, q1 = 1 + index of the next scan probe; q1 == 0:
-		 * the re-match probe at s - 1 comes first */
-		uint32_t s = 1, q1 = 1;
-		uint32_t epoch = kFilterEpochs;
-		bool fin = false;
-		uint32_t first4;
-		__builtin_memcpy(&first4, src, 4);
-		const uint32_t chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
-
-		/* the lanes' bytes and bucket ids, fetched one step ahead */
-		uint32_t raw[2][4], sid[2];
-		auto place = [&]() {
-			const uint32_t p0n = s + q1 - 2;
-			uint32_t pa = p0n + lane, pb = p0n + 64 + lane;
-			bool va = pa < ip_limit, vb = pb < ip_limit;
-			if (q1 > 32) {
-				/* sparse: the next 64 probes of the stride rule, in half 0 (:542-544) */
-				pa = scan_pos(s, q1 - 1 + lane);
-				va = scan_pos(s, q1 + lane) <= ip_limit;
-				vb = false;
-			}
-			pa = va ? pa : 0u;
-			pb = vb ? pb : 0u;
-			uint4 v0, v1;
-			__builtin_memcpy(&v0, src + pa, 16);
-			__builtin_memcpy(&v1, src + pb, 16);
-			sid[0] = ids[pa];
-			sid[1] = ids[pb];
-			raw[0][0] = v0.x, raw[0][1] = v0.y, raw[0][2] = v0.z, raw[0][3] = v0.w;
-			raw[1][0] = v1.x, raw[1][1] = v1.y, raw[1][2] = v1.z, raw[1][3] = v1.w;
-		};
-		place();
-
-		uint32_t guard = 0; /* every step probes or inserts at least one new position: a logic error must not hang the GPU */
-		while (!fin && ++guard <= n) {
-			tick(0); /* (rest of the previous step: commit) */
-			if (PROF) {
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				pn_steps++;
-			}
-			tick(1); /* wait for the step's own bytes and ids */
-			const bool sparse_c = q1 > 32;
-			const uint32_t p0 = s + q1 - 2; /* dense: position of virtual lane 0 */
-			const uint32_t ulim = min(128u, ip_limit - p0); /* dense: virtual lanes in front of the scan limit */
-			uint32_t posv[2] = { p0 + lane, p0 + 64 + lane };
-			bool val[2] = { lane < ulim, 64 + lane < ulim };
-			if (sparse_c) {
-				posv[0] = scan_pos(s, q1 - 1 + lane);
-				val[0] = scan_pos(s, q1 + lane) <= ip_limit;
-				val[1] = false;
-			}
-			uint32_t me[2][4], slot[2], chk[2], cand[2], key[2], key2[2];
-			bool tabbed[2], spilled[2], maybe[2];
-#pragma unroll
-			for (int h = 0; h < 2; ++h) {
-#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					me[h][k] = raw[h][k];
-				const uint32_t prod = me[h][0] * kHashMul;
-				slot[h] = sid[h];
-				tabbed[h] = val[h] && slot[h] != kNoBucket;
-				chk[h] = (prod >> (shift - 1)) & 1u;
-				key[h] = slot[h] & smask;
-				key2[h] = ((slot[h] >> s_shift) ^ (slot[h] << (s_shift - 5))) & smask;
-				/* slot sharing inside a step: two small filters; see filter_tag() */
-				atomicMin(&S[key[h]], filter_tag(epoch, slot[h], 64u * h + lane, tabbed[h]));
-				atomicMin(&S2[key2[h]], filter_tag(epoch, kFilterSlots - slot[h], 64u * h + lane, tabbed[h]));
-				spilled[h] = SPILL && tabbed[h] && slot[h] >= dense_cap;
-				const bool in_lds = tabbed[h] && !spilled[h];
-				cand[h] = tab[in_lds ? slot[h] : 0u];
-				cand[h] = in_lds ? cand[h] : 0u;
-			}
-			if (SPILL && ballot64(spilled[0] || spilled[1])) {
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const uint32_t g = spill[spilled[h] ? slot[h] - dense_cap : 0u];
-					cand[h] = spilled[h] ? g : cand[h];
-				}
-			}
-			wave_lds_fence();
-			/* the candidates' 16 bytes are requested as soon as the table entries are there, in front
-			 * of the filters' read-back (dense steps; lanes without a candidate read position 0) */
-			uint4 w4[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
-#pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				maybe[h] = tabbed[h] && (cand[h] ? cand[h] >> 15 : chk0) == chk[h]; /* the candidate can match at all */
-				cand[h] &= 0x7fffu;
-			}
-			if (!sparse_c) {
-				__builtin_memcpy(&w4[0], src + (maybe[0] ? cand[0] : 0u), 16);
-				__builtin_memcpy(&w4[1], src + (maybe[1] ? cand[1] : 0u), 16);
-			}
-			uint64_t cm[2], tm[2]; /* flagged lanes, lanes that take part in the table */
-#pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				const uint32_t e1 = S[key[h]], e2 = S2[key2[h]];
-				cm[h] = ballot64(tabbed[h] & filter_flags(e1, e2, slot[h], 64u * h + lane));
-				tm[h] = ballot64(tabbed[h]);
-			}
-			if (--epoch == 0) {
-				/* the tags' epoch field is about to wrap: start over with empty filters */
-				wave_lds_fence();
-				uint4 *s4 = reinterpret_cast<uint4 *>(S);
-				for (uint32_t k = lane; k < ((2 * A.s_entries) >> 2); k += 64)
-					s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-				wave_lds_fence();
-				epoch = kFilterEpochs;
-			}
-			tick(2); /* filters + table */
-
-			uint32_t e_final; /* last virtual lane whose table write is committed */
-			bool inside[2] = { false, false };
-			uint2 rec[2] = { make_uint2(0, 0), make_uint2(0, 0) };
-			bool rec_mine[2] = { false, false };
-			uint32_t rec_idx[2] = { 0, 0 };
-
-			if (sparse_c) {
-				/* ---- sparse step (half 0 only): ends at its first match, and in front of the first
-				 * lane that shares a slot with an earlier one ---- */
-				const uint64_t imask = ~ballot64(val[0]);
-				const uint32_t c1 = cm[0] ? first_lane(cm[0]) : 64u;
-				const uint32_t v = imask ? first_lane(imask) : 64u;
-				const uint32_t ul = min(c1, v);
-				const bool gathered = lane < ul && maybe[0];
-				__builtin_memcpy(&w4[0], src + (gathered ? cand[0] : 0u), 16);
-				const uint64_t xlo = ((uint64_t)(me[0][1] ^ w4[0].y) << 32) | (me[0][0] ^ w4[0].x);
-				const uint64_t xhi = ((uint64_t)(me[0][3] ^ w4[0].w) << 32) | (me[0][2] ^ w4[0].z);
-				const uint32_t ml = gathered ? common_prefix16(xlo, xhi) : 0u;
-				const uint64_t matchmask = ballot64(lane < ul && ml >= 4);
-				if (matchmask == 0) {
-					e_final = ul - 1;
-					if (ul == v && v < 64)
-						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
-					else
-						q1 += ul;
-				} else {
-					const uint32_t i = first_lane(matchmask);
-					e_final = i;
-					const uint32_t base = rdlane(posv[0], i), cnd = rdlane(cand[0], i);
-					uint32_t L = rdlane(ml, i);
-					if (L == kLocalMatch && base + L < n)
-						L += extend(cnd, base);
-					if (lane == 0)
-						R[nev] = pack_record(next_emit, base, cnd, L);
-					++nev;
-					const uint32_t ip = base + L;
-					next_emit = ip;
-					if (ip >= ip_limit)
-						fin = true; /* :585-586 */
-					s = ip + 1;
-					q1 = 0;
-				}
-				if (PROF)
-					pn_sparse++;
-				place();
-			} else {
-				/* ---- dense step: virtual lane v = 64 h + L holds position p0 + v; v = 0 is insert-only ---- */
-				uint32_t mlen[2], cl[2], nx[2];
-				uint64_t mm[2], wide[2];
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const uint64_t xlo = ((uint64_t)(me[h][1] ^ w4[h].y) << 32) | (me[h][0] ^ w4[h].x);
-					const uint64_t xhi = ((uint64_t)(me[h][3] ^ w4[h].w) << 32) | (me[h][2] ^ w4[h].z);
-					mlen[h] = maybe[h] ? common_prefix16(xlo, xhi) : 0u;
-				}
-				if (PROF) {
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					pn_tabbed += __builtin_popcountll(tm[0]) + __builtin_popcountll(tm[1]);
-					pn_gathered += __builtin_popcountll(ballot64(maybe[0])) + __builtin_popcountll(ballot64(maybe[1]));
-					pn_flagged += __builtin_popcountll(cm[0]) + __builtin_popcountll(cm[1]);
-				}
-				tick(3); /* candidate gather */
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					mm[h] = ballot64(mlen[h] >= 4);
-					wide[h] = ballot64(mlen[h] == kLocalMatch && posv[h] + kLocalMatch < n);
-					cl[h] = 64u * h + lane + mlen[h]; /* virtual lane of the re-match probe after my match */
-				}
-				mm[0] &= ~1ull;
-				if (PROF)
-					pn_match4 += __builtin_popcountll(mm[0]) + __builtin_popcountll(mm[1]);
-				/* flagged lanes are stops of the chain like matches: what they hold is decided when
-				 * (and if) the chain gets there */
-				const uint64_t stop0 = mm[0] | cm[0], stop1 = mm[1] | cm[1];
-				const uint64_t sp0 = wide[0] | cm[0], sp1 = wide[1] | cm[1]; /* stops that are not plain matches */
-				/* nx = the next stop of the chain behind my copy: 128: the re-match probe falls outside
-				 * the usable lanes; 129: none of the 33 probes behind the copy is a stop; v | 256: that
-				 * stop is a special lane */
-				{
-					const uint32_t c = cl[0]; /* 1 .. 79 for the lanes that matter */
-					const uint64_t w = c < 64 ? (stop0 >> (c & 63u)) | (stop1 << ((64u - c) & 63u)) : stop1 >> (c & 63u);
-					const uint32_t fm = w ? (uint32_t)__builtin_ctzll(w) : 64u;
-					const uint32_t j = c + fm;
-					const bool in = fm <= 32 && j <= 127;
-					const uint32_t sp = (uint32_t)((j < 64 ? sp0 >> (j & 63u) : sp1 >> (j & 63u)) & 1u);
-					nx[0] = c >= ulim ? 128u : in ? j | (sp << 8) : 129u;
-				}
-				{
-					const uint32_t c = cl[1]; /* 64 .. 143 */
-					const uint64_t w = c < 128 ? stop1 >> (c & 63u) : 0ull;
-					const uint32_t fm = w ? (uint32_t)__builtin_ctzll(w) : 64u;
-					const uint32_t j = c + fm;
-					const bool in = fm <= 32 && j <= 127;
-					const uint32_t sp = (uint32_t)((sp1 >> (j & 63u)) & 1u);
-					nx[1] = c >= ulim ? 128u : in ? j | (sp << 8) : 129u;
-				}
-				auto vbit = [&](uint64_t m0, uint64_t m1, uint32_t j) -> uint32_t {
-					return (uint32_t)((j < 64 ? m0 >> j : m1 >> (j - 64)) & 1u); /* j < 128 */
-				};
-				/* the same as nx for a copy that ends in front of virtual lane cc, on the scalar unit */
-				auto scalar_next = [&](uint32_t cc) -> uint32_t {
-					if (cc >= ulim)
-						return 128u;
-					uint64_t w;
-					if (cc < 64)
-						w = (stop0 >> cc) | (cc ? stop1 << (64 - cc) : 0ull);
-					else
-						w = stop1 >> (cc - 64); /* cc < ulim <= 128 */
-					const uint32_t fm = w ? (uint32_t)__builtin_ctzll(w) : 64u;
-					const uint32_t j = cc + fm;
-					if (fm > 32 || j > 127)
-						return 129u;
-					return j | (vbit(sp0, sp1, j) << 8);
-				};
-				/* the first segment: lanes 1 .. lim0 are what is left of the current scan's stride-1
-				 * probes (lim0 <= 33: all of them in half 0) */
-				const uint32_t lim0 = 33 - q1;
-				uint32_t t;
-				{
-					const uint32_t i0 = stop0 ? first_lane(stop0) : 64u;
-					t = i0 <= lim0 ? i0 | (((uint32_t)(sp0 >> (i0 & 63u)) & 1u) << 8) : 129u;
-				}
-				uint64_t taken0 = 0, taken1 = 0; /* lanes whose match is part of the chain */
-				tick(4); /* match lengths, next-stop table */
-				/* virtual lane of the end of the chain's last copy so far (the chain has one) */
-				auto last_cl = [&]() -> uint32_t {
-					return taken1 ? rdlane(cl[1], 63u - (uint32_t)__builtin_clzll(taken1))
-						      : rdlane(cl[0], 63u - (uint32_t)__builtin_clzll(taken0));
-				};
-				for (;;) {
-					/* plain matches: hop from match to match (readlane and bitset use the low six bits
-					 * of the virtual lane) */
-					while (t < 64) {
-						const uint32_t i = t;
-						t = rdlane(nx[0], i);
-						asm("s_bitset1_b64 %0, %1" : "+s"(taken0) : "s"(i));
-					}
-					while (t < 128) {
-						const uint32_t i = t;
-						t = rdlane(nx[1], i);
-						asm("s_bitset1_b64 %0, %1" : "+s"(taken1) : "s"(i));
-					}
-					if (t < 256)
-						break;
-					const uint32_t j = t & 127u, l = j & 63u;
-					const bool hi = j >= 64;
-					uint32_t L = hi ? rdlane(mlen[1], l) : rdlane(mlen[0], l);
-					uint32_t cnd = hi ? rdlane(cand[1], l) : rdlane(cand[0], l);
-					if (PROF)
-						pn_special++;
-					if (vbit(cm[0], cm[1], j)) {
-						/* ---- the chain probes a flagged lane ----
-						 * Its candidate is the latest position inserted for its slot: the highest virtual
-						 * lane below it that this step inserts (not strictly inside a copy of the chain)
-						 * and that has the same slot -- whose bytes are that lane's own 16 bytes -- else
-						 * the table value it already compared with. */
-						const uint32_t slot_j = hi ? rdlane(slot[1], l) : rdlane(slot[0], l);
-						const uint64_t belowl = (1ull << l) - 1;
-						uint64_t same0 = ballot64(slot[0] == slot_j) & tm[0] & (hi ? ~0ull : belowl);
-						uint64_t same1 = hi ? ballot64(slot[1] == slot_j) & tm[1] & belowl : 0ull;
-						if (same0 | same1) {
-							/* drop the sharers that lie strictly inside a copy taken so far */
-							const uint64_t b0 = taken0 & lt_mask, b1 = taken1 & lt_mask;
-							const uint32_t j0 = b0 ? 63u - (uint32_t)__builtin_clzll(b0) : 0u;
-							const uint32_t j1 = b1 ? 63u - (uint32_t)__builtin_clzll(b1) : 0u;
-							const uint32_t cp0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j0 << 2), (int)cl[0]);
-							uint32_t cp1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j1 << 2), (int)cl[1]);
-							const uint32_t c0last = taken0 ? rdlane(cl[0], 63u - (uint32_t)__builtin_clzll(taken0)) : 0u;
-							cp1 = b1 ? cp1 : c0last;
-							same0 &= ~ballot64(b0 != 0 && lane + 1 < cp0);
-							same1 &= ~ballot64((b1 != 0 || taken0 != 0) && 64 + lane + 1 < cp1);
-						}
-						if (same0 | same1) {
-							const bool from1 = same1 != 0;
-							const uint32_t jj = 63u - (uint32_t)__builtin_clzll(from1 ? same1 : same0);
-							uint32_t o[4];
-#pragma unroll
-							for (int k = 0; k < 4; ++k)
-								o[k] = from1 ? rdlane(me[1][k], jj) : rdlane(me[0][k], jj);
-							uint32_t ml;
-							if (hi) {
-								const uint64_t ylo = ((uint64_t)(me[1][1] ^ o[1]) << 32) | (me[1][0] ^ o[0]);
-								const uint64_t yhi = ((uint64_t)(me[1][3] ^ o[3]) << 32) | (me[1][2] ^ o[2]);
-								ml = common_prefix16(ylo, yhi);
-							} else {
-								const uint64_t ylo = ((uint64_t)(me[0][1] ^ o[1]) << 32) | (me[0][0] ^ o[0]);
-								const uint64_t yhi = ((uint64_t)(me[0][3] ^ o[3]) << 32) | (me[0][2] ^ o[2]);
-								ml = common_prefix16(ylo, yhi);
-							}
-							L = rdlane(ml, l);
-							cnd = p0 + (from1 ? 64u : 0u) + jj;
-						}
-						if (L < 4) {
-							/* no match: on to the next stop of the current window */
-							const uint32_t lim_cur = (taken0 | taken1) ? last_cl() + 32 : lim0;
-							uint32_t i2 = 128;
-							if (!hi) {
-								const uint64_t m = l < 63 ? stop0 & ((~0ull) << (l + 1)) : 0ull;
-								i2 = m ? first_lane(m) : stop1 ? 64u + first_lane(stop1) : 128u;
-							} else {
-								const uint64_t m = l < 63 ? stop1 & ((~0ull) << (l + 1)) : 0ull;
-								i2 = m ? 64u + first_lane(m) : 128u;
-							}
-							t = (i2 > lim_cur || i2 > 127) ? 129u : i2 | (vbit(sp0, sp1, i2) << 8);
-							continue;
-						}
-					}
-					if (L == kLocalMatch && p0 + j + kLocalMatch < n) {
-						/* longer than the lane-local cap: extend it wave-wide (it may leave the step) */
-						L = kLocalMatch + extend(cnd, p0 + j);
-					}
-					if (hi) {
-						if (lane == l) {
-							mlen[1] = L;
-							cl[1] = j + L;
-							cand[1] = cnd;
-						}
-						taken1 |= 1ull << l;
-					} else {
-						if (lane == l) {
-							mlen[0] = L;
-							cl[0] = j + L;
-							cand[0] = cnd;
-						}
-						taken0 |= 1ull << l;
-					}
-					t = scalar_next(j + L);
-				}
-				tick(5); /* chain walk */
-				if (PROF)
-					pn_hops += __builtin_popcountll(taken0) + __builtin_popcountll(taken1);
-				/* ---- where the chain left the step (see parse_lean) ---- */
-				const uint32_t emit0 = next_emit, nev0 = nev;
-				const bool any = (taken0 | taken1) != 0;
-				const uint32_t l0 = 63u - (uint32_t)__builtin_clzll(taken0 | 1);
-				const uint32_t l1 = 63u - (uint32_t)__builtin_clzll(taken1 | 1);
-				const uint32_t c0last = rdlane(cl[0], l0); /* (no copy in half 0: lane 0's, unused) */
-				const uint32_t c = taken1 ? rdlane(cl[1], l1) : c0last;
-				const uint32_t last = taken1 ? 64 + l1 : l0;
-				const uint32_t ip = p0 + c;
-				const bool end_a = t == 128;
-				const uint32_t lim = any ? c + 32 : lim0;
-				const uint32_t e = min(lim, ulim - 1);
-				e_final = end_a ? last : e;
-				fin = end_a ? ip >= ip_limit /* :585-586 */ : (ulim <= lim && ulim < 128);
-				next_emit = any ? ip : next_emit;
-				q1 = end_a ? 0u : any ? e + 1 - c : q1 + e;
-				s = any ? ip + 1 : s;
-				/* the cursor of the next step is known: fetch its bytes now (after the last step the
-				 * loads are harmless: an invalid lane reads position 0) */
-				place();
-				tick(6); /* cursor update, next step's loads issued */
-				/* ---- records of the taken matches, built by their own lanes ---- */
-				if (any) {
-					const uint64_t b0 = taken0 & lt_mask, b1 = taken1 & lt_mask;
-					const uint32_t j0 = b0 ? 63u - (uint32_t)__builtin_clzll(b0) : 0u;
-					const uint32_t j1 = b1 ? 63u - (uint32_t)__builtin_clzll(b1) : 0u;
-					const uint32_t cp0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j0 << 2), (int)cl[0]);
-					uint32_t cp1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j1 << 2), (int)cl[1]);
-					cp1 = b1 ? cp1 : c0last;
-					const bool has0 = b0 != 0, has1 = b1 != 0 || taken0 != 0;
-					const uint32_t n0 = (uint32_t)__builtin_popcountll(taken0);
-					rec_mine[0] = (taken0 >> lane) & 1;
-					rec_mine[1] = (taken1 >> lane) & 1;
-					inside[0] = has0 && lane + 1 < cp0; /* strictly inside a taken copy: never inserted */
-					inside[1] = has1 && 64 + lane + 1 < cp1;
-					rec_idx[0] = nev0 + (uint32_t)__builtin_popcountll(b0);
-					rec_idx[1] = nev0 + n0 + (uint32_t)__builtin_popcountll(b1);
-					rec[0] = pack_record(has0 ? p0 + cp0 : emit0, posv[0], cand[0], mlen[0]);
-					rec[1] = pack_record(has1 ? p0 + cp1 : emit0, posv[1], cand[1], mlen[1]);
-					nev = nev0 + n0 + (uint32_t)__builtin_popcountll(taken1);
-				}
-			}
-			tick(7); /* records built */
-			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
-			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
-			 * behind the stores would also sit out the stores' round trip. */
-			asm volatile(""
-				     : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]), "+v"(sid[0]),
-				       "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[1][2]), "+v"(raw[1][3]), "+v"(sid[1]));
-			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
-			if (rec_mine[0])
-				R[rec_idx[0]] = rec[0];
-			if (rec_mine[1])
-				R[rec_idx[1]] = rec[1];
-			/* commit table[slot] = position for every lane that was probed or inserted
-			 * (:550, :589, :593): virtual lanes 0..e_final except those inside a copy.  Half 0 is
-			 * written first, so a half-1 lane with the same slot wins as it must; inside ONE half
-			 * only the last of several lanes with one slot may write. */
-#pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				bool commit = 64u * h + lane <= e_final && !inside[h] && tabbed[h];
-				const uint64_t cmt = ballot64(commit);
-				uint64_t fl = cm[h] & cmt;
-				if (fl) {
-					uint64_t dead = 0;
-					if (SPILL || __builtin_popcountll(fl) <= 6) {
-						do {
-							const uint32_t x = first_lane(fl);
-							fl &= fl - 1;
-							dead |= ballot64(slot[h] == rdlane(slot[h], x)) & ((1ull << x) - 1);
-						} while (fl);
-					} else {
-						/* many sharers (runs): settle it through the table entries themselves (see parse_lean) */
-						bool pend = commit, wr = commit;
-						for (;;) {
-							if (wr)
-								tab[slot[h]] = (uint16_t)lane;
-							wave_lds_fence();
-							const uint32_t w = tab[pend ? slot[h] : 0u];
-							wave_lds_fence();
-							dead |= ballot64(pend && lane < w);
-							pend = pend && lane >= w;
-							wr = pend && lane > w;
-							if (!ballot64(wr))
-								break;
-						}
-					}
-					if ((dead >> lane) & 1)
-						commit = false;
-				}
-				if (commit && !spilled[h])
-					tab[slot[h]] = (uint16_t)(posv[h] | (chk[h] << 15));
-				if (SPILL && commit && spilled[h])
-					spill[slot[h] - dense_cap] = (uint16_t)(posv[h] | (chk[h] << 15));
-				wave_lds_fence();
-			}
-		}
-		stuck = !fin;
-	}
-
-	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
-	if (next_emit < n) {
-		if (lane == 0)
-			R[nev] = pack_record(next_emit, n, n, 0);
-		++nev;
-	}
-	if (lane == 0)
-		A.rec_cnt[F.c] = stuck ? kNoRecords : nev; /* (never parsed: the emit kernel reports the block as failed) */
-	if (PROF && lane == 0) {
-		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-		atomicAdd(&A.prof[0], t_end - pt_begin);
-		for (int k = 0; k < 9; ++k)
-			atomicAdd(&A.prof[1 + k], pt[k]);
-		atomicAdd(&A.prof[10], pn_steps);
-		atomicAdd(&A.prof[11], pn_hops);
-		atomicAdd(&A.prof[12], pn_special);
-		atomicAdd(&A.prof[13], pn_sparse);
-		atomicAdd(&A.prof[14], 1ull);
-		atomicAdd(&A.prof[16], pn_tabbed);
-		atomicAdd(&A.prof[17], pn_gathered);
-		atomicAdd(&A.prof[18], pn_match4);
-		atomicAdd(&A.prof[19], pn_flagged);
-	}
-}
-
-/* table indexed by dense bucket ids, in LDS: prologue, then the 128-wide parser */
-extern "C" __global__ void __launch_bounds__(64, 4) snappy_parse_fragments_dense_wide(CompressArgs A)
-{
-	Frag F;
-	if (!frag_setup(A, F, false))
-		return;
-	const uint32_t nb = dense_prologue(A, F);
-	if (nb == kNoRecords)
-		return;
-	if (nb > A.dense_cap)
-		parse_wide<true>(A, F);
-	else
-		parse_wide<false>(A, F);
-}
-
-extern "C" __global__ void __launch_bounds__(64, 4) snappy_parse_fragments_dense_wide_prof(CompressArgs A)
-{
-	Frag F;
-	if (!frag_setup(A, F, false))
-		return;
-	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-	const uint32_t nb = dense_prologue(A, F);
-	if (nb == kNoRecords)
-		return;
-	if (threadIdx.x == 0)
-		atomicAdd(&A.prof[15], __builtin_amdgcn_s_memtime() - t0);
-	if (nb > A.dense_cap)
-		parse_wide<true, true>(A, F);
-	else
-		parse_wide<false, true>(A, F);
 }
 
 /* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
@@ -3887,7 +3288,6 @@ struct Knobs {
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
 	bool ok;
 	bool old_parser; /* CSNAPPY_HIP_PARSER=old: the round-2 step loop (A/B timing) */
-	bool lean64;     /* CSNAPPY_HIP_PARSER=lean: 64-position steps for the dense table too */
 };
 
 bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
@@ -3905,11 +3305,9 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true, false, false };
-	if (const char *e = getenv("CSNAPPY_HIP_PARSER")) {
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true, false };
+	if (const char *e = getenv("CSNAPPY_HIP_PARSER"))
 		k.old_parser = !strcmp(e, "old");
-		k.lean64 = !strcmp(e, "lean");
-	}
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -4223,10 +3621,6 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	}
 	if (lean_prof)
 		k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof);
-	/* full fragments on the dense table: steps of 128 positions */
-	if (P.tab == TAB_LDS_DENSE && !kn.old_parser && !kn.lean64 && P.spill_cap)
-		k1 = g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_wide_prof)
-				: reinterpret_cast<const void *>(snappy_parse_fragments_dense_wide);
 	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
 	const void *ks = reinterpret_cast<const void *>(snappy_parse_fragments_dense_spill_prof);
 	if (P.spill_cap && g_prof_buf &&
