@@ -2088,59 +2088,66 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 constexpr uint32_t kEmitWaves = 4;
 constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records) */
 
+/* small blocks (pages): one wave per block, chunks in order, no size pass.  (A kernel of its own:
+ * inlined beside the workgroup-per-block path below, the two copies of emit_chunk cost the
+ * kernel 128 VGPRs and 120 spilled SGPRs.) */
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pages(CompressArgs A)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	/* small blocks (pages): one wave per block, chunks in order, no size pass */
+	const uint32_t b = blockIdx.x * kEmitWaves + wv;
+	if (b >= A.emit_blocks)
+		return;
+	const uint32_t blk = A.blk_base + b;
+	const uint32_t len = A.in_len[blk];
+	if (len > A.max_in_len) {
+		if (lane == 0)
+			A.out_len[blk] = 0xffffffffu;
+		return;
+	}
+	uint8_t *dst = A.out + A.out_off[blk];
+	uint32_t pos = 0;
+	if (A.mode == CSNAPPY_HIP_STREAM) {
+		pos = varint_len(len);
+		if (lane < pos)
+			dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
+	}
+	const uint32_t cnt = A.rec_cnt[b]; /* fpb == 1 */
+	if (cnt >= kWantGlobal) {
+		/* (never parsed: see below) */
+		if (lane == 0)
+			A.out_len[blk] = 0xffffffffu;
+		return;
+	}
+	const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)b * A.rec_cap);
+	const uint8_t *src = A.in + A.in_off[blk];
+	/* records are fetched two chunks ahead, literal bytes one chunk ahead */
+	ChunkIn cur, nxt;
+	nxt.r = fetch_record(R, 0, min(64u, cnt), lane);
+	uint2 r2 = cnt > 64 ? fetch_record(R, 64, min(64u, cnt - 64), lane) : make_uint2(0, 0);
+	if (cnt)
+		fetch_literal(nxt, min(64u, cnt), src, len, lane);
+	for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
+		cur = nxt;
+		nxt.r = r2;
+		if (r0 + 128 < cnt)
+			r2 = fetch_record(R, r0 + 128, min(64u, cnt - r0 - 128), lane);
+		if (r0 + 64 < cnt)
+			fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
+		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane);
+	}
+	if (lane == 0)
+		A.out_len[blk] = pos;
+	return;
+}
+
 extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blocks(CompressArgs A)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
 	__shared__ uint32_t chunk_tot[kMaxChunks];
 	__shared__ uint32_t chunk_base[kMaxChunks + 1];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (A.emit_wave_per_block) {
-		/* small blocks (pages): one wave per block, chunks in order, no size pass */
-		const uint32_t b = blockIdx.x * kEmitWaves + wv;
-		if (b >= A.emit_blocks)
-			return;
-		const uint32_t blk = A.blk_base + b;
-		const uint32_t len = A.in_len[blk];
-		if (len > A.max_in_len) {
-			if (lane == 0)
-				A.out_len[blk] = 0xffffffffu;
-			return;
-		}
-		uint8_t *dst = A.out + A.out_off[blk];
-		uint32_t pos = 0;
-		if (A.mode == CSNAPPY_HIP_STREAM) {
-			pos = varint_len(len);
-			if (lane < pos)
-				dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
-		}
-		const uint32_t cnt = A.rec_cnt[b]; /* fpb == 1 */
-		if (cnt >= kWantGlobal) {
-			/* (never parsed: see below) */
-			if (lane == 0)
-				A.out_len[blk] = 0xffffffffu;
-			return;
-		}
-		const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)b * A.rec_cap);
-		const uint8_t *src = A.in + A.in_off[blk];
-		/* records are fetched two chunks ahead, literal bytes one chunk ahead */
-		ChunkIn cur, nxt;
-		nxt.r = fetch_record(R, 0, min(64u, cnt), lane);
-		uint2 r2 = cnt > 64 ? fetch_record(R, 64, min(64u, cnt - 64), lane) : make_uint2(0, 0);
-		if (cnt)
-			fetch_literal(nxt, min(64u, cnt), src, len, lane);
-		for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
-			cur = nxt;
-			nxt.r = r2;
-			if (r0 + 128 < cnt)
-				r2 = fetch_record(R, r0 + 128, min(64u, cnt - r0 - 128), lane);
-			if (r0 + 64 < cnt)
-				fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
-			pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane);
-		}
-		if (lane == 0)
-			A.out_len[blk] = pos;
-		return;
-	}
 	const uint32_t blk = A.blk_base + blockIdx.x;
 	const uint32_t len = A.in_len[blk];
 	if (len > A.max_in_len) {
@@ -2505,15 +2512,23 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			uint8_t *pd = dst + op;
 			const uint32_t body = L & ~15u;
 			for (uint32_t j0 = lane * 16; j0 < body; j0 += 4096) {
-				uint4 v[4];
-#pragma unroll
-				for (int kk = 0; kk < 4; ++kk)
-					if (j0 + 1024u * kk < body)
-						__builtin_memcpy(&v[kk], ps + j0 + 1024u * kk, 16);
-#pragma unroll
-				for (int kk = 0; kk < 4; ++kk)
-					if (j0 + 1024u * kk < body)
-						__builtin_memcpy(pd + j0 + 1024u * kk, &v[kk], 16);
+				/* (unconditional loads from a clamped address -- body >= 16 here: the first element
+				 * did not fit the staging -- keep the four pieces in registers; loaded under the
+				 * condition they are stored under they become an array in scratch, 80 B per lane that
+				 * every wave of the kernel pays the set-up of) */
+				const uint32_t last16 = body - 16;
+				uint4 v0, v1, v2, v3;
+				__builtin_memcpy(&v0, ps + min(j0, last16), 16);
+				__builtin_memcpy(&v1, ps + min(j0 + 1024u, last16), 16);
+				__builtin_memcpy(&v2, ps + min(j0 + 2048u, last16), 16);
+				__builtin_memcpy(&v3, ps + min(j0 + 3072u, last16), 16);
+				__builtin_memcpy(pd + j0, &v0, 16);
+				if (j0 + 1024u < body)
+					__builtin_memcpy(pd + j0 + 1024u, &v1, 16);
+				if (j0 + 2048u < body)
+					__builtin_memcpy(pd + j0 + 2048u, &v2, 16);
+				if (j0 + 3072u < body)
+					__builtin_memcpy(pd + j0 + 3072u, &v3, 16);
 			}
 			if (body + lane < L)
 				pd[body + lane] = ps[body + lane];
@@ -3698,8 +3713,11 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		t.start();
 		A.emit_wave_per_block = fpb == 1 && max_in_len <= 8192;
 		A.emit_blocks = nb;
-		hipLaunchKernelGGL(snappy_emit_blocks, dim3(A.emit_wave_per_block ? (nb + kEmitWaves - 1) / kEmitWaves : nb),
-				   dim3(64 * kEmitWaves), 0, st, A);
+		if (A.emit_wave_per_block)
+			hipLaunchKernelGGL(snappy_emit_pages, dim3((nb + kEmitWaves - 1) / kEmitWaves), dim3(64 * kEmitWaves), 0,
+					   st, A);
+		else
+			hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb), dim3(64 * kEmitWaves), 0, st, A);
 		t.stop(1);
 		if (!hip_ok(hipGetLastError(), "launch snappy_emit_blocks"))
 			return CSNAPPY_HIP_E_RUNTIME;
