@@ -2615,7 +2615,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 
 	if (lane == 0) {
 		A.status[blk] = status;
-		A.produced[blk] = status == CSNAPPY_E_OK ? op : 0;
+		/* on -3 / -5 the decoded prefix is in dst, as after the reference's write-as-you-go
+		 * SnappyArrayWriter (csnappy_decompress.c:258-317): its length is reported too (header
+		 * errors -1 / -2 happen before anything is written: op is 0 then) */
+		A.produced[blk] = op;
 	}
 }
 

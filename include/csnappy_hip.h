@@ -72,8 +72,12 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
  *   d_out_cap[b]    STREAM: dst_len of csnappy_decompress; FRAGMENT: *dst_len on entry of
  *                   csnappy_decompress_noheader
  *   d_status[b]     CSNAPPY_E_* code the reference call would return (0, -1, -2, -3, -5)
- *   d_produced[b]   bytes produced when status is 0 (FRAGMENT: *dst_len on exit), else 0
- * Bytes of the output slot beyond `produced` are never written.  in_len[b] and out_cap[b] must
+ *   d_produced[b]   bytes produced (FRAGMENT, status 0: *dst_len on exit).  With status -3 / -5
+ *                   it is the length of the decoded prefix that is in the slot: the elements in
+ *                   front of the failing one, which the reference's write-as-you-go writer has
+ *                   stored by then too (csnappy_decompress.c:258-317); 0 with -1 / -2
+ * Bytes of the output slot beyond `produced` are never written when status is 0, and never beyond
+ * out_cap[b] otherwise.  in_len[b] and out_cap[b] must
  * be below 2^32 - 2^16 (the kernels keep 32-bit cursors like the reference's uint32 API).
  */
 int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
@@ -85,8 +89,8 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
  * Decompress ONE stream body of any length with the whole device.  Same contract
  * as csnappy_decompress_noheader(d_in, in_len, d_out, &ulength) (csnappy_decompress.c:319-387):
  * `ulength` is *dst_len on entry (the room in d_out), d_status[0] receives the reference's return
- * code, d_produced[0] the bytes produced when it is 0 (*dst_len on exit; it may be less than
- * ulength).  csnappy_decompress (:390-415) is this call after the length header has been parsed
+ * code, d_produced[0] the bytes produced (status 0: *dst_len on exit, possibly less than ulength;
+ * -3 / -5: the length of the decoded prefix in d_out).  csnappy_decompress (:390-415) is this call after the length header has been parsed
  * (the header's value is `ulength`).
  *
  * A pre-pass indexes the tags of the body with one wave per 4 KiB and looks for the elements that

@@ -17,7 +17,8 @@ from csnappy_amd import api
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+GOLDEN = os.path.join(HERE, "golden")
+GOLD = json.load(open(os.path.join(GOLDEN, "golden.json")))
 
 
 def sha(b):
@@ -272,6 +273,7 @@ def test_corrupted_streams_match_oracle_status(torch, chk):
             streams.append(bytes(m))
             caps.append(int(rng.choice([len(x), len(x) + 7, max(len(x) - 3, 0), 2 * len(x) + 64])))
     st, pr, outs = gpu_decompress(torch, streams, caps, api.STREAM)
+    nfail_prefix = 0
     for i, (s, cap) in enumerate(zip(streams, caps)):
         want_rc, want_out = chk.decompress(s, cap)
         assert st[i] == want_rc, (i, s.hex()[:60], cap)
@@ -279,6 +281,14 @@ def test_corrupted_streams_match_oracle_status(torch, chk):
             n = P.get_uncompressed_length(s)
             _, prod, body = chk.decompress_noheader(s[n[0]:], cap)
             assert outs[i] == body and pr[i] == prod
+        elif want_rc in (api.E_OUTPUT_OVERRUN, api.E_DATA_MALFORMED):
+            # the reference stores as it goes (csnappy_decompress.c:258-317): the decoded prefix is
+            # in dst after a failure, and `produced` says how long ours is
+            nfail_prefix += int(pr[i]) > 0
+            assert outs[i] == want_out[:int(pr[i])], (i, s.hex()[:60], cap, int(pr[i]))
+        else:
+            assert pr[i] == 0
+    assert nfail_prefix > 50, "the damaged streams should mostly fail behind a decoded prefix"
     # noheader form on the same bodies
     from test_oracle import _body_has_truncated_tag
     bodies = [s[P.get_uncompressed_length(s)[0]:] if P.get_uncompressed_length(s)[0] > 0 else s for s in streams]
@@ -290,6 +300,37 @@ def test_corrupted_streams_match_oracle_status(torch, chk):
         assert st2[i] == rc, (i, s.hex()[:60], cap)
         if rc == 0:
             assert pr2[i] == prod and outs2[i] == body
+
+
+def test_legacy_failing_decompress_leaves_the_decoded_prefix(torch, chk):
+    """csnappy_decompress / _noheader through the legacy C ABI: after -3 / -5 dst holds what the
+    reference's writer has stored by then (csnappy_decompress.c:258-317)."""
+    P = oracle.Port()
+    rng = np.random.default_rng(5)
+    text = api.generate_host(api.WG_TEXT, 0xC5A90001, 3, 1, 40000).tobytes()
+    good = P.compress(text, 15)
+    hdr = P.get_uncompressed_length(good)[0]
+    seen = 0
+    for trial in range(40):
+        m = bytearray(good)
+        at = int(rng.integers(len(m) // 4, len(m)))
+        m[at] = 0x03  # a COPY_4 tag in the middle of things: offset far beyond what was produced
+        m[at + 1:at + 5] = b"\xff\xff\xff\x7f"
+        m = bytes(m[:int(rng.integers(at + 5, len(m) + 1))])
+        from test_oracle import _has_truncated_tag
+        if _has_truncated_tag(m):
+            continue
+        want_rc, want_dst = chk.decompress(m, len(text))
+        rc, dst = api.decompress(m, len(text))
+        assert rc == want_rc
+        if rc in (api.E_OUTPUT_OVERRUN, api.E_DATA_MALFORMED):
+            # the prefix both wrote: up to the first byte where our zero-filled dst was left alone
+            k = len(dst.rstrip(b"\0"))
+            assert k > 0 and dst[:k] == want_dst[:k]  # (not the plain text: the damage may sit in a literal)
+            seen += 1
+            rc2, _, _ = api.decompress_noheader(m[hdr:], len(text))
+            assert rc2 == chk.decompress_noheader(m[hdr:], len(text))[0]
+    assert seen >= 10
 
 
 def test_truncated_tag_is_malformed(torch):
@@ -396,6 +437,50 @@ def test_long_stream_is_decoded_fragment_by_fragment(torch, chk, urls, nbytes):
     d_out = torch.zeros(len(data) + 70000, dtype=torch.uint8, device="cuda")
     st, produced, fast = api.decompress_stream(body, len(data) + 70000, d_out)
     assert (st, produced, fast) == (0, len(data), True) and bytes(d_out[:produced].cpu().numpy()) == data
+
+
+def test_stream_index_regression_vector(torch, chk):
+    """The 813 547-byte stream of sparse matches (literals of a few hundred bytes between short
+    copies) on which round 2's soak found the stream index wrong: most segment entries take the
+    last-tag table instead of the speculative parse.  Committed as found
+    (tests/golden/stream_index_sparse.snappy.gz); expected bytes = the reference's decode."""
+    stream = gzip.decompress(open(os.path.join(GOLDEN, "stream_index_sparse.snappy.gz"), "rb").read())
+    assert len(stream) == 328300 and sha(stream).startswith("f008019aa3d36d4a")
+    hdr, ulen = chk.get_uncompressed_length(stream)
+    assert (hdr, ulen) == (3, 813547)
+    rc, want = chk.decompress(stream, ulen)
+    assert rc == 0 and sha(want).startswith("33bc95657da2b30e")
+    st, out, fast = _stream_call(torch, stream, chk)
+    assert st == 0 and out == want and fast
+    assert api.decompress(stream, ulen) == (0, want)
+
+
+def test_foreign_streams_from_google_snappy(torch, chk):
+    """Streams written by Google's snappy (pyarrow's bundled copy, tests/golden/make_foreign.py):
+    64 KiB blocks, its own literal / copy choices.  Through the stream call (the index must
+    recognise the 64 KiB grain of the long ones), the batch call and the legacy call."""
+    from golden.make_foreign import foreign_inputs
+    index = json.load(open(os.path.join(GOLDEN, "foreign.json")))["streams"]
+    inputs = foreign_inputs()
+    streams = {}
+    for name, meta in index.items():
+        data = inputs[name]
+        assert sha(data) == meta["input_sha256"], "the frozen generators changed"
+        stream = open(os.path.join(GOLDEN, f"foreign_{name}.snappy"), "rb").read()
+        assert sha(stream) == meta["stream_sha256"]
+        streams[name] = stream
+        st, out, fast = _stream_call(torch, stream, chk)
+        assert st == 0 and out == data, name
+        # Copies of this encoder cross the 32 KiB lines inside its 64 KiB blocks, so a long stream
+        # decodes by fragments only if the index recognised the 64 KiB grain (a fragment with a
+        # copy reaching out of it fails and the verdict falls back to one wave).  A stream of a
+        # single block may or may not have an element at 32 KiB: no claim there.
+        if len(data) > 128 * 1024:
+            assert fast, name
+        assert api.decompress(stream, len(data)) == (0, data), name
+    names = sorted(streams)
+    st, pr, outs = gpu_decompress(torch, [streams[k] for k in names], [len(inputs[k]) for k in names], api.STREAM)
+    assert (st == 0).all() and [bytes(o) for o in outs] == [inputs[k] for k in names]
 
 
 def test_long_foreign_stream_falls_back_to_one_wave(torch, chk):

@@ -374,3 +374,24 @@ def test_framing_restatement_crc32c_known_answers_and_spec_streams(port):
     bad[14] ^= 1
     assert frame.decode(bytes(bad), dec, ulen)[0] == frame.E_CRC
     assert frame.decode(f, dec, ulen, dst_cap=len(x) - 1)[0] == frame.E_OUTPUT_INSUF
+
+
+def test_foreign_and_regression_fixtures_decode_with_the_oracle(port, golden_dir):
+    """The decoder fixtures round 3 added -- Google-snappy streams (tests/golden/make_foreign.py)
+    and the stream on which round 2's soak found the stream index wrong -- against the
+    restatement and, when present, the compiled reference (the GPU tests decode the same files)."""
+    import hashlib
+    from golden.make_foreign import foreign_inputs
+    index = json.load(open(os.path.join(golden_dir, "foreign.json")))["streams"]
+    inputs = foreign_inputs()
+    codecs = [port] + ([oracle.Ref()] if oracle.have_ref() else [])
+    for name, meta in index.items():
+        stream = open(os.path.join(golden_dir, f"foreign_{name}.snappy"), "rb").read()
+        assert hashlib.sha256(stream).hexdigest() == meta["stream_sha256"]
+        assert hashlib.sha256(inputs[name]).hexdigest() == meta["input_sha256"]
+        for c in codecs:
+            assert c.decompress(stream, len(inputs[name])) == (0, inputs[name]), (name, c.kind)
+    stream = gzip.open(os.path.join(golden_dir, "stream_index_sparse.snappy.gz")).read()
+    outs = {c.kind: c.decompress(stream, 813547) for c in codecs}
+    for kind, (rc, out) in outs.items():
+        assert rc == 0 and hashlib.sha256(out).hexdigest().startswith("33bc95657da2b30e"), kind
