@@ -161,7 +161,73 @@ def verify_against_reference(torch, api, d_in, b, d_out, chunk, block, p, mode, 
             "checker": codec.kind}
 
 
-def main():
+class GpuEngine:
+    """The product path bench.py measures: device buffers are torch tensors, every codec call goes
+    through the C-ABI (csnappy_amd.api).  tests/test_bench_ranks_cpu.py drives run() with an
+    engine of the same shape in which the CPU checker stands in for the kernels, so that the
+    rank / world plumbing below (block ranges, slowest-rank reduction, the gather) is exercised by
+    a 2-rank gloo test before it ever meets eight GPUs."""
+    backend = "nccl"
+
+    def __init__(self, local_rank):
+        import torch
+        from csnappy_amd import api
+        api.require_device()
+        torch.cuda.set_device(local_rank)
+        self.torch, self.api, self.local_rank = torch, api, local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def init_dist(self, dist):
+        dist.init_process_group("nccl", device_id=self.device)
+
+    def generate(self, kind, seed, first, nb, block, urls=None):
+        torch = self.torch
+        if kind >= 0:
+            return self.api.generate(kind, seed, first, nb, block)
+        rep = torch.from_numpy(np.frombuffer(urls, dtype=np.uint8).copy()).cuda()
+        idx = (torch.arange(nb * block, device="cuda", dtype=torch.int64) + first * block) % len(urls)
+        return rep[idx]
+
+    def batch(self, lens):
+        return self.api.Batch(lens)
+
+    def zeros(self, n, dtype):
+        return self.torch.zeros(n, dtype=dtype, device="cuda")
+
+    def full(self, n, value, dtype):
+        return self.torch.full((n,), value, dtype=dtype, device="cuda")
+
+    def compress(self, src, b, cnt, d_out, p, mode):
+        self.api.compress_batch(src, b.d_in_off[:cnt], b.d_in_len[:cnt], b.max_in_len, d_out, b.d_out_off[:cnt],
+                                b.d_out_len[:cnt], p, mode, b.d_ws)
+
+    def decompress(self, d_out, b, cnt, d_back, cap, status, produced, mode):
+        self.api.decompress_batch(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt], d_back, b.d_in_off[:cnt], cap[:cnt],
+                                  status[:cnt], produced[:cnt], mode)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def timing(self, on):
+        if on:
+            self.api.get_kernel_timing()
+        self.api.set_kernel_timing(on)
+
+    def kernel_times(self):
+        return self.api.get_kernel_timing()
+
+    def copy_bandwidth(self):
+        return measured_copy_bandwidth(self.torch, 1 << 30)
+
+    def verify(self, d_in, b, d_out, chunk, block, p, mode, nv):
+        return verify_against_reference(self.torch, self.api, d_in, b, d_out, chunk, block, p, mode, nv)
+
+    def time_gather(self, d_out, b, dist, world):
+        from csnappy_amd import shard
+        return shard.time_gather_compacted(d_out, b, dist, world)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -178,27 +244,17 @@ def main():
     ap.add_argument("--verify-gib", type=float, default=1.0,
                     help="outside the timed region, compare the compressed bytes and lengths of the first "
                          "this-many GiB of blocks with the CPU reference (0 = round-trip check only)")
-    ap.add_argument("--gather", action="store_true",
-                    help="also time an RCCL all_gather of the compacted per-rank streams (reported "
-                         "separately; never part of `value`)")
-    args = ap.parse_args()
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="also time the RCCL gather of the compacted per-rank streams to rank 0 (reported "
+                         "separately; never part of `value`).  Default: on when there is more than one rank")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
+    return ap.parse_args(argv)
 
-    import torch
-    from csnappy_amd import api
+
+def run(args, eng, dist, rank, world):
+    """One bench run on this rank.  -> the JSON record on rank 0, None elsewhere."""
     from csnappy_amd import shard
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    api.require_device()
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+    torch = eng.torch
     kind, seed, block, p, mode, desc = WORKLOADS[args.workload]
     block = args.block or block
     p = args.p or p
@@ -207,34 +263,27 @@ def main():
 
     # ---- input resident in HBM -------------------------------------------------------------------
     urls = None
-    if kind >= 0:
-        d_in = api.generate(kind, seed, first, nb, block)
-    else:
+    if kind < 0:
         urls = open(os.path.join(ROOT, "tests", "golden", "urls.10K"), "rb").read()
-        rep = torch.from_numpy(np.frombuffer(urls, dtype=np.uint8).copy()).cuda()
-        idx = (torch.arange(nb * block, device="cuda", dtype=torch.int64) + first * block) % len(urls)
-        d_in = rep[idx]
-        del idx
+    d_in = eng.generate(kind, seed, first, nb, block, urls)
     # the batch is processed in chunks of <= chunk_gib (one chunk for the default 1 GiB workload)
     cb = max(1, min(nb, int(args.chunk_gib * 2 ** 30) // block))  # blocks per chunk
     chunks = [(lo, min(cb, nb - lo)) for lo in range(0, nb, cb)]
-    b = api.Batch([block] * cb)
-    d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
-    d_back = torch.zeros(cb * block, dtype=torch.uint8, device="cuda")
-    cap = torch.full((cb,), block, dtype=torch.int32, device="cuda")
-    status = torch.full((cb,), -99, dtype=torch.int32, device="cuda")
-    produced = torch.zeros(cb, dtype=torch.int32, device="cuda")
-    comp_total = torch.zeros(1, dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
+    b = eng.batch([block] * cb)
+    d_out = eng.zeros(b.out_bytes, torch.uint8)
+    d_back = eng.zeros(cb * block, torch.uint8)
+    cap = eng.full(cb, block, torch.int32)
+    status = eng.full(cb, -99, torch.int32)
+    produced = eng.zeros(cb, torch.int32)
+    comp_total = eng.zeros(1, torch.int64)
+    eng.sync()
 
     def run_chunk(lo, cnt, check=False):
         src = d_in[lo * block:(lo + cnt) * block]
-        api.compress_batch(src, b.d_in_off[:cnt], b.d_in_len[:cnt], b.max_in_len, d_out, b.d_out_off[:cnt],
-                           b.d_out_len[:cnt], p, mode, b.d_ws)
-        api.decompress_batch(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt], d_back, b.d_in_off[:cnt], cap[:cnt],
-                             status[:cnt], produced[:cnt], mode)
+        eng.compress(src, b, cnt, d_out, p, mode)
+        eng.decompress(d_out, b, cnt, d_back, cap, status, produced, mode)
         if check:  # outside the timed region only
-            torch.cuda.synchronize()
+            eng.sync()
             assert (status[:cnt] == 0).all().item(), "decompress reported an error"
             assert torch.equal(d_back[:cnt * block], src), "round trip differs from the input"
             comp_total.add_(b.d_out_len[:cnt].to(torch.int64).sum())
@@ -244,10 +293,10 @@ def main():
             run_chunk(lo, cnt, check)
 
     def barrier():
-        torch.cuda.synchronize()
+        eng.sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        eng.sync()
 
     # results are checked outside the timed region: every block of every chunk round-trips
     step(check=True)
@@ -256,30 +305,29 @@ def main():
     # every compressed length, and the sha256 of the compacted stream
     bit_exact = None
     if rank == 0 and args.verify_gib > 0:
-        bit_exact = verify_against_reference(torch, api, d_in, b, d_out, chunks[0], block, p, mode,
-                                             min(chunks[0][1], max(1, int(args.verify_gib * 2 ** 30) // block)))
+        bit_exact = eng.verify(d_in, b, d_out, chunks[0], block, p, mode,
+                               min(chunks[0][1], max(1, int(args.verify_gib * 2 ** 30) // block)))
     for _ in range(max(0, args.warmup - 1)):
         step()
-    torch.cuda.synchronize()
+    eng.sync()
 
     # ---- timed region: exactly K steps ----------------------------------------------------------
-    api.get_kernel_timing()
-    api.set_kernel_timing(True)
+    eng.timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    api.set_kernel_timing(False)
-    kt = api.get_kernel_timing()
+    eng.timing(False)
+    kt = eng.kernel_times()
 
     t_max, t_min, ranks_seen = elapsed, elapsed, 1
     n_bytes = nb * block
     kt_ms = [kt[k][0] for k in sorted(kt)]
     if dist is not None:
         ranks_seen = dist.get_world_size()
-        t = torch.tensor([elapsed, -elapsed] + kt_ms, dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, -elapsed] + kt_ms, dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank, also per kernel
         t_max, t_min = t[0].item(), -t[1].item()
         kt = {k: (t[2 + i].item(), kt[k][1]) for i, k in enumerate(sorted(kt))}
@@ -288,14 +336,15 @@ def main():
     kernels = {k: {"avg_ms": round(ms / max(c, 1), 4), "launches": c,
                    "ms_per_step": round(ms / args.steps, 4)} for k, (ms, c) in kt.items()}
 
+    # the one collective of the path: the final stream to rank 0 (throughput is reported
+    # both without and with it).  On by default as soon as there is more than one rank.
     gather = None
-    if args.gather and dist is not None:
-        gather = shard.time_gather_compacted(d_out, b, dist, world)  # the last chunk's output
+    want_gather = args.gather if args.gather is not None else world > 1
+    if want_gather and dist is not None:
+        gather = eng.time_gather(d_out, b, dist, world)  # the last chunk's output
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     # ---- roofline of the dominant operation (this GPU) -------------------------------------------
     # algorithmic bytes per batch: compress N_in + C_out, decompress C_in + N_out.
@@ -311,7 +360,7 @@ def main():
     achieved = dom_alg / dom_s / 1e9 if dom_s > 0 else 0.0
     traffic = load_measured_traffic(args.workload, p, dom_kernels) if (nch == 1 and args.gib == 1.0
                                                                        and args.block is None) else None
-    peak_measured = measured_copy_bandwidth(torch, 1 << 30)
+    peak_measured = eng.copy_bandwidth()
     roofline = {"bound": "hbm", "kernel": dom_kernels[0], "operation": dom, "kernels_of_operation": list(dom_kernels),
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -352,14 +401,34 @@ def main():
         "roofline": roofline,
     }
     if gather is not None:
+        # the same round trip with the gather of the final stream added to every step's time
+        # (the last chunk's stream stands for the step's: one chunk in the default workload)
         out["gather"] = gather
+        out["value_with_gather"] = round(n_bytes * world / (t_max / args.steps + gather["ms"] / 1e3 * nch) / 2 ** 30, 4)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(kind, seed, block, p, mode, nb, args.cpu_seconds, urls)
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": os.cpu_count(),
                                    "kind": "port", "sample": f"failed: {e!r}"}
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    eng = GpuEngine(local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
+        import torch.distributed as dist
+        eng.init_dist(dist)
+    out = run(args, eng, dist, rank, world)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -111,6 +111,14 @@ def lib():
     return L
 
 
+def reload_knobs():
+    """Tests only: make the library read the CSNAPPY_HIP_* environment knobs again (it reads them
+    once, at the first batch call)."""
+    f = lib().csnappy_hip_debug_reload_knobs
+    f.restype, f.argtypes = None, []
+    f()
+
+
 def device_count():
     return lib().csnappy_hip_device_count()
 

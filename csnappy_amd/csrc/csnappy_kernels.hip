@@ -3301,8 +3301,9 @@ uint32_t record_cap(uint32_t n)
 	return n / 4 + 8;
 }
 
-/* Experiment knobs (environment, read on every batch call so that a test can switch them; each is
- * range-checked and a bad value makes the batch call fail with CSNAPPY_HIP_E_ARG):
+/* Experiment knobs (environment, read ONCE -- at the first batch call of the process; tests that
+ * switch them call the debug entry csnappy_hip_debug_reload_knobs() -- each range-checked; a bad
+ * value makes every batch call fail with CSNAPPY_HIP_E_ARG):
  *   CSNAPPY_HIP_TABLE      auto | hash | dense | global   where the hash table lives
  *   CSNAPPY_HIP_DENSE_CAP  256..16384 (multiple of 64)    entries of the dense LDS table
  *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        entries per conflict filter
@@ -3354,6 +3355,16 @@ Knobs read_knobs()
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_SAMPLE_MIN", 0, 2048, &k.sample_min);
 	return k;
+}
+
+/* the knobs as the process sees them: read at first use, never again on the launch path */
+Knobs g_knobs;
+std::once_flag g_knobs_once;
+
+const Knobs &knobs()
+{
+	std::call_once(g_knobs_once, [] { g_knobs = read_knobs(); });
+	return g_knobs;
 }
 
 /* Launch geometry of the parser for table power p and fragments of <= maxfrag bytes. */
@@ -3549,6 +3560,14 @@ void csnappy_hip_debug_set_profile_buffer(void *d_buf)
 	g_prof_buf = static_cast<unsigned long long *>(d_buf);
 }
 
+/* debug only (not in the public header): read the CSNAPPY_HIP_* environment knobs again.  For
+ * tests that switch table placements inside one process; not to be called while a batch call runs. */
+void csnappy_hip_debug_reload_knobs(void)
+{
+	(void)knobs();
+	g_knobs = read_knobs();
+}
+
 void csnappy_hip_set_kernel_timing(int enable)
 {
 	g_timing = enable != 0;
@@ -3577,7 +3596,7 @@ size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len
 {
 	if (nblocks == 0)
 		return 65536;
-	return (size_t)plan_workspace(nblocks, max_in_len, read_knobs()).total;
+	return (size_t)plan_workspace(nblocks, max_in_len, knobs()).total;
 }
 
 int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
@@ -3589,7 +3608,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return CSNAPPY_HIP_E_ARG;
 	if (mode == CSNAPPY_HIP_FRAGMENT && max_in_len > kFragment)
 		return CSNAPPY_HIP_E_ARG;
-	const Knobs kn = read_knobs();
+	const Knobs kn = knobs();
 	if (!kn.ok)
 		return CSNAPPY_HIP_E_ARG;
 	if (nblocks == 0)

@@ -128,8 +128,8 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
  * Thread safety: the batch calls keep no state between calls and may be issued from several
  * threads (each with its own buffers, workspace and, preferably, stream); the timing list below is
  * mutex-guarded.  csnappy_hip_last_error() is per thread.  The CSNAPPY_HIP_* environment knobs
- * (experiments; see csnappy_kernels.hip) are read and range-checked on every compress batch call;
- * a bad value makes the call return CSNAPPY_HIP_E_ARG.
+ * (experiments; see csnappy_kernels.hip) are read and range-checked once, at the first batch call
+ * of the process; a bad value makes every compress batch call return CSNAPPY_HIP_E_ARG.
  *
  * Per-kernel timing for bench.py: while enabled, the batch calls record a hipEvent pair on
  * `stream` around each kernel (nothing synchronises in the launch path).

@@ -53,6 +53,7 @@ def soak(budget, seed=None):
             mode = int(rng.integers(0, 2))
             p = int(rng.integers(9, 17))
             os.environ["CSNAPPY_HIP_TABLE"] = str(rng.choice(["auto", "hash", "dense", "global"]))
+            api.reload_knobs()
             nb = int(rng.integers(1, 300))
             top = 32768 if mode else int(rng.choice([300, 5000, 32768, 65536, 200000]))
             lens = [int(rng.choice([0, 1, 14, 15, 16, rng.integers(0, top + 1), top])) for _ in range(nb)]
@@ -84,6 +85,7 @@ def soak(budget, seed=None):
             os.environ.pop("CSNAPPY_HIP_TABLE", None)
         else:
             os.environ["CSNAPPY_HIP_TABLE"] = saved
+        api.reload_knobs()
     return rounds, blocks_done, chk.kind
 
 

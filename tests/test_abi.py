@@ -134,4 +134,9 @@ def test_experiment_knobs_are_range_checked(name, value, monkeypatch):
     call = lambda: L.csnappy_hip_compress_batch(fake, fake, fake, 4, 65536, fake, fake, fake, 16, api.STREAM,
                                                 fake, ws, None)
     monkeypatch.setenv(name, value)
-    assert call() == -101
+    api.reload_knobs()  # the library reads its knobs once; this is the debug entry that re-reads them
+    try:
+        assert call() == -101
+    finally:
+        monkeypatch.delenv(name)
+        api.reload_knobs()

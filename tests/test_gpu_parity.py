@@ -752,6 +752,14 @@ def _force_placement(monkeypatch, placement):
         monkeypatch.setenv("CSNAPPY_HIP_SPILL_CAP", "0")
     else:
         monkeypatch.setenv("CSNAPPY_HIP_TABLE", placement)
+    api.reload_knobs()  # (the library reads the knobs once; see the fixture below for the way back)
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back_to_the_environment():
+    """monkeypatch restores the environment after a test; make the library follow"""
+    yield
+    api.reload_knobs()
 
 
 @pytest.mark.parametrize("placement", PLACEMENTS)
