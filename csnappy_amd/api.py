@@ -30,6 +30,7 @@ HIP_SYMBOLS = [
     "csnappy_hip_get_kernel_timing", "csnappy_hip_workload_generate", "csnappy_hip_compact_batch",
     "csnappy_workload_generate_host", "csnappy_hip_decompress_stream_workspace_size",
     "csnappy_hip_decompress_stream", "csnappy_hip_decompress_stream_took_fast_path",
+    "csnappy_hip_dense_offsets_workspace_size", "csnappy_hip_dense_offsets", "csnappy_hip_gather_layout",
 ]
 
 FRAME_SYMBOLS = [
@@ -89,6 +90,12 @@ def lib():
     L.csnappy_hip_decompress_stream_took_fast_path.argtypes = [vp, u32, u32, vp]
     L.csnappy_hip_compact_batch.restype = i32
     L.csnappy_hip_compact_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    L.csnappy_hip_dense_offsets_workspace_size.restype = C.c_size_t
+    L.csnappy_hip_dense_offsets_workspace_size.argtypes = [u32]
+    L.csnappy_hip_dense_offsets.restype = i32
+    L.csnappy_hip_dense_offsets.argtypes = [vp, u32, vp, vp, vp, C.c_size_t, vp]
+    L.csnappy_hip_gather_layout.restype = None
+    L.csnappy_hip_gather_layout.argtypes = [vp, u32, vp, vp]
     L.csnappy_hip_set_kernel_timing.restype = None
     L.csnappy_hip_set_kernel_timing.argtypes = [i32]
     L.csnappy_hip_get_kernel_timing.restype = None
@@ -270,6 +277,30 @@ def decompress_stream(d_body, ulength, d_out):
     fast = lib().csnappy_hip_decompress_stream_took_fast_path(ws.data_ptr(), n, ulength, _stream())
     status, produced = res.cpu().tolist()
     return status, produced & 0xFFFFFFFF, bool(fast)
+
+
+def dense_offsets(out_len):
+    """Exclusive sum of the compressed lengths on the device (csnappy_hip_dense_offsets):
+    -> (int64 offsets tensor, total bytes)"""
+    import torch
+    n = out_len.numel()
+    off = torch.empty(max(n, 1), dtype=torch.int64, device=out_len.device)
+    total = torch.zeros(1, dtype=torch.int64, device=out_len.device)
+    need = lib().csnappy_hip_dense_offsets_workspace_size(n)
+    ws = torch.empty(need // 8 + 1, dtype=torch.int64, device=out_len.device)
+    rc = lib().csnappy_hip_dense_offsets(out_len.data_ptr(), n, off.data_ptr(), total.data_ptr(), ws.data_ptr(),
+                                         ws.numel() * 8, _stream())
+    _check(rc, "csnappy_hip_dense_offsets")
+    return off[:n], int(total.item())
+
+
+def gather_layout(rank_bytes):
+    """csnappy_hip_gather_layout on a list of per-rank byte counts -> (offsets list, total)"""
+    rb = np.asarray(rank_bytes, dtype=np.uint64)
+    off = np.zeros(len(rb), dtype=np.uint64)
+    total = C.c_uint64(0)
+    lib().csnappy_hip_gather_layout(rb.ctypes.data, len(rb), off.ctypes.data, C.byref(total))
+    return [int(x) for x in off], int(total.value)
 
 
 def compact_batch(d_out, out_off, out_len, dense_off, dense):

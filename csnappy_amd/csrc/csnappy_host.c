@@ -17,8 +17,7 @@
  *   - re-entrant: calls are serialised on one mutex-guarded device context (plumbing: one
  *     synchronous H2D -> launch -> D2H per call; the device buffers grow to the largest call and
  *     are kept for the life of the process)
- * Differences a caller can observe (also in INTEGRATION.md):
- *   - on -3 / -5 the reference has written the bytes decoded so far into dst; here dst is untouched
+ * Difference a caller can observe (also in INTEGRATION.md):
  *   - a failing HIP runtime (no device, hipMalloc) returns CSNAPPY_E_HIP_UNAVAILABLE (-100)
  */
 #ifndef CSNAPPY_HOST_ARITH_ONLY /* (the sanitizer driver of the test tree compiles only the two arithmetic entry points) */
@@ -32,6 +31,19 @@
 #endif
 
 #include "../../include/csnappy.h"
+
+/* Where every rank's compacted stream lands in the assembled one (include/csnappy_hip.h): the
+ * arithmetic between the size exchange and the grouped send/recv of the gather.  Host only. */
+void csnappy_hip_gather_layout(const uint64_t *rank_bytes, uint32_t nranks, uint64_t *rank_off, uint64_t *total)
+{
+	uint64_t run = 0;
+	uint32_t r;
+	for (r = 0; r < nranks; r++) {
+		rank_off[r] = run;
+		run += rank_bytes[r];
+	}
+	*total = run;
+}
 
 #ifndef CSNAPPY_HOST_ARITH_ONLY
 struct buf {

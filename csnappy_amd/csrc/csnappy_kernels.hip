@@ -3142,6 +3142,81 @@ snappy_compact_stream(const uint8_t *out, const uint64_t *out_off, const uint32_
 		d[tail + tid] = s[tail + tid];
 }
 
+/* exclusive sum of the compressed lengths (the dense offsets compact_batch wants), in three small
+ * launches: per-tile sums (4096 lengths per 256-thread tile), a one-workgroup scan of the tile
+ * sums, and the offsets inside every tile */
+constexpr uint32_t kScanTile = 4096;
+
+DEVINL uint64_t block_excl_scan64(uint64_t v, uint64_t *wsum, uint64_t *total)
+{
+	/* 256 threads: wave scans on two 32-bit halves would lose carries; a shared-memory ladder is
+	 * plenty for a 256-element scan */
+	const uint32_t tid = threadIdx.x;
+	wsum[tid] = v;
+	__syncthreads();
+	for (uint32_t d = 1; d < 256; d <<= 1) {
+		const uint64_t add = tid >= d ? wsum[tid - d] : 0;
+		__syncthreads();
+		wsum[tid] += add;
+		__syncthreads();
+	}
+	*total = wsum[255];
+	const uint64_t incl = wsum[tid];
+	__syncthreads();
+	return incl - v;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+snappy_length_tile_sums(const uint32_t *len, uint32_t n, uint64_t *tile_sum)
+{
+	__shared__ uint64_t wsum[256];
+	const uint32_t base = blockIdx.x * kScanTile;
+	uint64_t v = 0;
+	for (uint32_t k = threadIdx.x; k < kScanTile; k += 256)
+		if (base + k < n)
+			v += len[base + k];
+	uint64_t total;
+	(void)block_excl_scan64(v, wsum, &total);
+	if (threadIdx.x == 0)
+		tile_sum[blockIdx.x] = total;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+snappy_length_tile_scan(uint64_t *tile_sum, uint32_t ntiles, uint64_t *total_out)
+{
+	__shared__ uint64_t wsum[256];
+	uint64_t run = 0;
+	for (uint32_t b0 = 0; b0 < ntiles; b0 += 256) {
+		const uint32_t i = b0 + threadIdx.x;
+		const uint64_t v = i < ntiles ? tile_sum[i] : 0;
+		uint64_t total;
+		const uint64_t ex = block_excl_scan64(v, wsum, &total);
+		if (i < ntiles)
+			tile_sum[i] = run + ex;
+		run += total;
+	}
+	if (threadIdx.x == 0)
+		*total_out = run;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+snappy_length_offsets(const uint32_t *len, uint32_t n, const uint64_t *tile_base, uint64_t *off)
+{
+	__shared__ uint64_t wsum[256];
+	const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * (kScanTile / 256); /* 16 consecutive per thread */
+	uint64_t v = 0;
+	for (uint32_t k = 0; k < kScanTile / 256; ++k)
+		if (base + k < n)
+			v += len[base + k];
+	uint64_t total;
+	uint64_t run = tile_base[blockIdx.x] + block_excl_scan64(v, wsum, &total);
+	for (uint32_t k = 0; k < kScanTile / 256; ++k)
+		if (base + k < n) {
+			off[base + k] = run;
+			run += len[base + k];
+		}
+}
+
 /* ==========================================================================================
  * CRC-32C of byte ranges (Snappy framing format, include/csnappy_frame.h): one wave per range.
  * Every lane runs the byte-wise table CRC over its 1/64th of the range; the 64 partial CRCs are
@@ -3925,6 +4000,31 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
 			   static_cast<hipStream_t>(stream), static_cast<const uint8_t *>(d_out), d_out_off,
 			   d_out_len, d_dense_off, static_cast<uint8_t *>(d_dense));
 	if (!hip_ok(hipGetLastError(), "launch snappy_compact_stream"))
+		return CSNAPPY_HIP_E_RUNTIME;
+	return 0;
+}
+
+size_t csnappy_hip_dense_offsets_workspace_size(uint32_t nblocks)
+{
+	return ((size_t)(nblocks + kScanTile - 1) / kScanTile + 1) * 8;
+}
+
+int csnappy_hip_dense_offsets(const uint32_t *d_out_len, uint32_t nblocks, uint64_t *d_dense_off, uint64_t *d_total,
+			      void *d_workspace, size_t workspace_bytes, void *stream)
+{
+	if (workspace_bytes < csnappy_hip_dense_offsets_workspace_size(nblocks) ||
+	    (reinterpret_cast<uintptr_t>(d_workspace) & 7))
+		return CSNAPPY_HIP_E_WORKSPACE;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	uint64_t *tiles = static_cast<uint64_t *>(d_workspace);
+	const uint32_t ntiles = (nblocks + kScanTile - 1) / kScanTile;
+	if (ntiles)
+		hipLaunchKernelGGL(snappy_length_tile_sums, dim3(ntiles), dim3(256), 0, st, d_out_len, nblocks, tiles);
+	hipLaunchKernelGGL(snappy_length_tile_scan, dim3(1), dim3(256), 0, st, tiles, ntiles, d_total);
+	if (ntiles)
+		hipLaunchKernelGGL(snappy_length_offsets, dim3(ntiles), dim3(256), 0, st, d_out_len, nblocks, tiles,
+				   d_dense_off);
+	if (!hip_ok(hipGetLastError(), "launch snappy_length_*"))
 		return CSNAPPY_HIP_E_RUNTIME;
 	return 0;
 }

@@ -38,7 +38,7 @@ def compact(d_out, d_out_off, d_out_len):
     -> (dense uint8 tensor, int64 dense offsets)"""
     import torch
     from . import api
-    off, total = dense_offsets(d_out_len)
+    off, total = api.dense_offsets(d_out_len) if d_out_len.is_cuda else dense_offsets(d_out_len)
     dense = torch.empty(max(total, 1), dtype=torch.uint8, device=d_out.device)
     api.compact_batch(d_out, d_out_off, d_out_len, off, dense)
     return dense[:total], off

@@ -125,6 +125,31 @@ int csnappy_hip_compact_batch(const void *d_out, const uint64_t *d_out_off, cons
 			      const uint64_t *d_dense_off, uint32_t nblocks, void *d_dense, void *stream);
 
 /*
+ * The pieces a plain-C caller needs to assemble the final stream (blocks shard
+ * across the GPUs of a node with no data-path collective; only the finished streams are gathered):
+ *
+ *   csnappy_hip_dense_offsets   exclusive sum of d_out_len[] on the device -> the d_dense_off[] that
+ *                               csnappy_hip_compact_batch takes, and the rank's byte count d_total[0]
+ *                               (workspace: csnappy_hip_dense_offsets_workspace_size bytes, 8-aligned)
+ *   csnappy_hip_compact_batch   (above) the rank's dense stream
+ *   csnappy_hip_gather_layout   host arithmetic: from every rank's byte count (one ncclAllGather of
+ *                               8 bytes per rank) each rank's offset in the assembled stream, and
+ *                               its total
+ *
+ * and then, with the caller's RCCL communicator, one grouped exchange: ncclGroupStart; the root
+ * posts ncclRecv(dst + rank_off[r], rank_bytes[r], ncclUint8, r, ...) for every peer, every peer
+ * ncclSend(its dense stream, ..., root, ...); ncclGroupEnd.  INTEGRATION.md section 4 has the
+ * whole sequence as a C function (tools/gather_rccl_example.c, compiled by the tests); the library
+ * itself does not link RCCL -- which RCCL (the system's, or the one bundled with a framework) is
+ * the caller's choice.
+ */
+size_t csnappy_hip_dense_offsets_workspace_size(uint32_t nblocks);
+int csnappy_hip_dense_offsets(const uint32_t *d_out_len, uint32_t nblocks, uint64_t *d_dense_off,
+			      uint64_t *d_total, void *d_workspace, size_t workspace_bytes, void *stream);
+void csnappy_hip_gather_layout(const uint64_t *rank_bytes, uint32_t nranks, uint64_t *rank_off,
+			       uint64_t *total);
+
+/*
  * Thread safety: the batch calls keep no state between calls and may be issued from several
  * threads (each with its own buffers, workspace and, preferably, stream); the timing list below is
  * mutex-guarded.  csnappy_hip_last_error() is per thread.  The CSNAPPY_HIP_* environment knobs

@@ -140,3 +140,17 @@ def test_experiment_knobs_are_range_checked(name, value, monkeypatch):
     finally:
         monkeypatch.delenv(name)
         api.reload_knobs()
+
+
+def test_gather_layout_and_the_c_gather_example():
+    """csnappy_hip_gather_layout is host arithmetic; tools/gather_rccl_example.c -- the C sequence
+    compact -> size exchange -> grouped ncclSend/ncclRecv that assembles the final stream of a
+    block-sharded batch -- must compile against the product header and the image's HIP and RCCL
+    headers (it cannot run here: one GPU per box)."""
+    import subprocess
+    assert api.gather_layout([5, 0, 7, 1 << 40]) == ([0, 5, 5, 12], 12 + (1 << 40))
+    assert api.gather_layout([]) == ([], 0)
+    src = os.path.join(ROOT, "tools", "gather_rccl_example.c")
+    r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I/opt/rocm/include", src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -483,6 +483,21 @@ def test_foreign_streams_from_google_snappy(torch, chk):
     assert (st == 0).all() and [bytes(o) for o in outs] == [inputs[k] for k in names]
 
 
+def test_dense_offsets_on_the_device(torch):
+    """csnappy_hip_dense_offsets (what a C caller runs in front of csnappy_hip_compact_batch)
+    against a host cumsum: empty, one tile, tile edges, several tiles, lengths that need 64 bits."""
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 255, 256, 4095, 4096, 4097, 70001, 1 << 20):
+        lens = rng.integers(0, 76490, n, dtype=np.int64).astype(np.uint32)
+        if n == 70001:
+            lens[:] = 0xfffffff0  # 70001 x ~4 GiB: far beyond 32 bits
+        d = torch.from_numpy(lens.view(np.int32).copy()).cuda()
+        off, total = api.dense_offsets(d)
+        want = np.cumsum(lens.astype(np.uint64)) - lens.astype(np.uint64) if n else np.zeros(0, np.uint64)
+        assert total == int(lens.astype(np.uint64).sum())
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), want), n
+
+
 def test_long_foreign_stream_falls_back_to_one_wave(torch, chk):
     """Copies across 32 KiB of output (legal Snappy, never written by csnappy): the fragments cannot
     be decoded apart, the one-wave result is the answer."""
