@@ -145,6 +145,29 @@ DEVINL uint32_t wave_incl_scan_dpp(uint32_t x)
 	return x;
 }
 
+/* the same with max (values >= 0: lanes a shift leaves without a source contribute 0) */
+template <int CTRL, int ROW_MASK> DEVINL uint32_t dpp_max(uint32_t x)
+{
+	return max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false));
+}
+
+DEVINL uint32_t wave_incl_max_dpp(uint32_t x)
+{
+	x = dpp_max<0x111, 0xf>(x); /* row_shr:1 */
+	x = dpp_max<0x112, 0xf>(x); /* row_shr:2 */
+	x = dpp_max<0x114, 0xf>(x); /* row_shr:4 */
+	x = dpp_max<0x118, 0xf>(x); /* row_shr:8 */
+	x = dpp_max<0x142, 0xa>(x); /* row_bcast:15 -> rows 1 and 3 */
+	x = dpp_max<0x143, 0xc>(x); /* row_bcast:31 -> rows 2 and 3 */
+	return x;
+}
+
+/* lane L receives lane L-1's value, lane 0 receives 0 (wave_shr:1) */
+DEVINL uint32_t wave_shr1(uint32_t x)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
+
 /* exclusive prefix sum across the 64 lanes; *total receives the wave sum */
 DEVINL uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t *total)
 {
@@ -989,9 +1012,11 @@ __device__ __forceinline__ void parse_fragment_body(const CompressArgs &A, uint3
 				uint64_t fl = cmask & cm;
 				uint64_t dead = 0;
 				while (fl) {
-					const uint32_t x = first_lane(fl);
-					fl &= fl - 1;
-					dead |= ballot64(slot == rdlane(slot, x)) & cm & ((1ull << x) - 1);
+					/* one round per shared slot, highest lane first (runs: one slot on most lanes) */
+					const uint32_t x = 63u - (uint32_t)__builtin_clzll(fl);
+					const uint64_t same = ballot64(slot == rdlane(slot, x)) & cm;
+					dead |= same & ((1ull << x) - 1);
+					fl &= ~same;
 				}
 				if ((dead >> lane) & 1)
 					commit = false;
@@ -1255,15 +1280,24 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 			}
 		}
 	};
+	/* Equal hashes next to each other in a lane's eight (runs: all eight) are settled in registers:
+	 * one atomic for the group, and the slot is known to be hit twice.  (Without this, runs
+	 * serialise on one LDS word: G_low's prologue took 2.5x the time of text's.) */
 	sweep([&](const uint4 &v, uint32_t, uint32_t cntp) {
 		uint32_t hh[8], old[8];
+		bool first[8], twice[8];
 		hash8(v, hh);
 #pragma unroll
-		for (uint32_t k = 0; k < 8; ++k)
-			old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+		for (uint32_t k = 0; k < 8; ++k) {
+			first[k] = k < cntp && (k == 0 || hh[k] != hh[k - 1]);
+			twice[k] = k + 1 < cntp && hh[k + 1] == hh[k]; /* (on the group's members but its last) */
+		}
 #pragma unroll
 		for (uint32_t k = 0; k < 8; ++k)
-			if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
+			old[k] = first[k] ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k)
+			if (first[k] && (((old[k] >> (hh[k] & 31)) & 1u) || twice[k]))
 				atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
 	});
 	wave_lds_fence();
@@ -1697,10 +1731,12 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				/* ---- records of the taken matches, built by their own lanes ---- */
 				if (taken) {
 					const uint64_t below = taken & lt_mask;
-					const bool hasprev = below != 0;
-					const uint32_t jprev = hasprev ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
 					rec_mine = (taken >> lane) & 1;
+					/* cprev = where the nearest taken copy below me ends (0: none).  The ends grow
+					 * along the chain, so this is a running maximum over the lanes below: DPP row
+					 * shifts, no LDS round trip (a bpermute from the nearest taken lane did it before) */
+					const uint32_t cprev = wave_shr1(wave_incl_max_dpp(rec_mine ? cl : 0u));
+					const bool hasprev = cprev != 0;
 					const uint32_t lit_start = hasprev ? p0 + cprev : emit0;
 					inside = hasprev && lane + 1 < cprev; /* strictly inside a taken copy: never inserted */
 					rec_idx = nev0 + (uint32_t)__builtin_popcountll(below);
@@ -1729,32 +1765,16 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint64_t cm = ballot64(commit);
 				uint64_t fl = cmask & cm;
 				if (fl) {
+					/* one round per SLOT that several committed lanes share, highest lane first: it
+					 * keeps its write, the lower ones of its slot lose theirs (runs put one slot on
+					 * most of the 64 lanes: one round, not one per lane) */
 					uint64_t dead = 0;
-					if (SPILL || __builtin_popcountll(fl) <= 6) {
-						do {
-							const uint32_t x = first_lane(fl);
-							fl &= fl - 1;
-							dead |= ballot64(slot == rdlane(slot, x)) & ((1ull << x) - 1);
-						} while (fl);
-					} else {
-						/* many sharers (runs): settle it through the table entries themselves.  Every
-						 * round the pending lanes that lost to a LOWER lane write their lane number
-						 * again; a lane that reads back a higher one is dead.  The winner of a slot
-						 * only ever moves up, so this ends with the highest lane of every slot. */
-						bool pend = commit, wr = commit;
-						for (;;) {
-							if (wr)
-								tab[slot] = (uint16_t)lane;
-							wave_lds_fence();
-							const uint32_t w = tab[pend ? slot : 0u];
-							wave_lds_fence();
-							dead |= ballot64(pend && lane < w);
-							pend = pend && lane >= w;
-							wr = pend && lane > w;
-							if (!ballot64(wr))
-								break;
-						}
-					}
+					do {
+						const uint32_t x = 63u - (uint32_t)__builtin_clzll(fl);
+						const uint64_t same = ballot64(slot == rdlane(slot, x)) & cm;
+						dead |= same & ((1ull << x) - 1);
+						fl &= ~same;
+					} while (fl);
 					if ((dead >> lane) & 1)
 						commit = false;
 				}
