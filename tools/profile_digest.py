@@ -27,7 +27,9 @@ summary = {"bench_args": args, "kernels": {}, "pmc": {}, "per_batch": {}}
 
 def family(name):
     """compress runs as one or more chunk launches of one of its instantiations per batch call"""
-    return "snappy_parse_fragments" if name.startswith("snappy_parse_fragments") else name
+    if name.startswith("snappy_parse_fragments"):
+        return "snappy_parse_fragments"
+    return "snappy_emit_blocks" if name.startswith("snappy_emit_") else name  # (pages: snappy_emit_pages)
 for r in rows("stats/**/*kernel_stats.csv"):
     name = r.get("Name", "")
     if "snappy" in name or "workload" in name:
