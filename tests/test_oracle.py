@@ -278,6 +278,40 @@ def test_forwarding_step_model_is_bit_exact(port, urls):
             assert wm.compress_fragment_v4(bytes(pg), 13, fallback_cut=fc) == port.compress_fragment(pg, 13)
 
 
+def test_lean_step_model_is_bit_exact(port, urls):
+    """v5 of the model = round 3's step loop (parse_lean): the (s, q1) cursor, lane 0 insert-only,
+    the per-lane next-stop table, visits of flagged and cap-length lanes, the END_A / END_B cursor
+    update and the commit mask, restated on the CPU and held against the oracle."""
+    import wave_model as wm
+    frag = urls[400000:400000 + 32768]
+    for p in (16, 13, 9):
+        st = {}
+        assert wm.compress_fragment_v5(frag, p, stats=st) == port.compress_fragment(frag, p)
+        assert st["steps"] < len(frag) // 8
+    rng = np.random.default_rng(10)
+    visits = 0
+    for x, p in _fuzz_inputs(7, 260, 5000):
+        x = x[:32768]
+        s_entries = int(rng.choice([4, 64, min(1 << (p - 1), 1024)]))
+        lm = int(rng.choice([4, 8, 16]))
+        st = {}
+        assert wm.compress_fragment_v5(x.tobytes(), p, s_entries, stats=st, lm=lm) == \
+            port.compress_fragment(x, p), (len(x), p, s_entries, lm)
+        visits += st.get("visits", 0)
+    assert visits > 0
+    # every length around the margin and the first wave steps
+    base = bytes(urls[5000:5400])
+    for n in list(range(0, 100)) + [127, 128, 129, 191, 192, 193]:
+        assert wm.compress_fragment_v5(base[:n], 12) == port.compress_fragment(np.frombuffer(base[:n], np.uint8), 12), n
+    # runs (one slot on every lane) and heap-like pages
+    for blob in (b"\0" * 5000, b"ab" * 3000, b"abcdefgh" * 700 + b"x" + b"abcdefgh" * 50):
+        assert wm.compress_fragment_v5(blob, 14) == port.compress_fragment(np.frombuffer(blob, np.uint8), 14)
+    pages = api.generate_host(2, 0xC5A90004, 0, 32, 4096)
+    for i in range(32):
+        pg = pages[i * 4096:(i + 1) * 4096]
+        assert wm.compress_fragment_v5(bytes(pg), 13) == port.compress_fragment(pg, 13)
+
+
 # ---- batch drivers used by the GPU parity tests and the CPU baseline --------------------------
 def test_batch_drivers_match_single_calls(port, urls):
     b = api.Batch.uniform(len(urls), 65536, device=None)

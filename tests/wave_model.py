@@ -606,3 +606,177 @@ def compress_fragment_v4(F, p, s_entries=None, stats=None, lm=LM, fallback_cut=F
     if next_emit < n:
         records.append((next_emit, n - next_emit, 0, 0))
     return encode_records(F, records)
+
+
+def compress_fragment_v5(F, p, s_entries=None, stats=None, lm=LM):
+    """Round 3's step loop (parse_lean in csnappy_kernels.hip), statement by statement on the
+    scalar side: the cursor is (s, q1) -- the scan that starts at s has made q1 - 1 probes, q1 == 0
+    means "a copy just ended at s - 1: insert ip - 1, probe ip" -- lane 0 of a dense step is always
+    insert-only, the lanes in front of the scan limit are arithmetic, every lane precomputes the
+    next stop behind its own match (nx: 64 = the re-match probe falls outside the usable lanes,
+    65 = none of the 33 probes behind the copy is a stop, lane | 128 = that stop is special), the
+    chain follows nx and visits special lanes (flagged: shares its filter key with a lower lane;
+    wide: matches the whole lane-local window), and the step's end is read off the `taken` lanes.
+    s_entries small makes the filter raise false alarms, which the visits must survive."""
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 64
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    if s_entries is None:
+        s_entries = min(1 << (p - 1), 1024)
+    smask = s_entries - 1
+    records = []
+    next_emit = 0
+
+    def lcp(a, b, start, limit):
+        k = start
+        while k < limit and F[a + k] == F[b + k]:
+            k += 1
+        return k
+
+    if n > MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        s, q1 = 1, 1
+        fin = False
+        guard = 0
+        while not fin:
+            guard += 1
+            assert guard <= n, "the cursor stopped moving"
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            sparse = q1 > 32
+            p0 = s + q1 - 2
+            pos, valid = [0] * WAVE, [False] * WAVE
+            for l in range(WAVE):
+                if sparse:
+                    pos[l] = scan_pos(s, q1 - 1 + l)
+                    valid[l] = scan_pos(s, q1 + l) <= ip_limit
+                else:
+                    pos[l] = p0 + l
+                    valid[l] = pos[l] < ip_limit
+                if not valid[l]:
+                    pos[l] = 0
+            h = [((rd32(pos[l]) * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            tabbed = valid[:]
+            cand = [tab[h[l]] if tabbed[l] else 0 for l in range(WAVE)]
+            seen = {}
+            flagged = [False] * WAVE  # (a superset of the lanes that share their SLOT with a lower lane)
+            for l in range(WAVE):
+                if tabbed[l]:
+                    k = h[l] & smask
+                    if k in seen and l != 0:
+                        flagged[l] = True
+                    seen.setdefault(k, l)
+            if sparse:
+                v = next((l for l in range(WAVE) if not valid[l]), 64)
+                c1 = next((l for l in range(WAVE) if flagged[l]), 64)
+                ul = min(c1, v)
+                mlen = [lcp(cand[l], pos[l], 0, lm) if l < ul and tabbed[l] else 0 for l in range(WAVE)]
+                m = next((l for l in range(ul) if mlen[l] >= 4), None)
+                if m is None:
+                    e_final = ul - 1
+                    if ul == v and v < 64:
+                        fin = True
+                    else:
+                        q1 += ul
+                else:
+                    e_final = m
+                    base, cnd, L = pos[m], cand[m], mlen[m]
+                    if L == lm and base + L < n:
+                        L = lcp(cnd, base, lm, n - base)
+                    records.append((next_emit, base - next_emit, base - cnd, L))
+                    ip = base + L
+                    next_emit = ip
+                    if ip >= ip_limit:
+                        fin = True
+                    s, q1 = ip + 1, 0
+                for l in range(WAVE):
+                    if l <= e_final and tabbed[l]:
+                        tab[h[l]] = pos[l]
+                continue
+
+            # ---- dense step ----
+            ulim = min(64, ip_limit - p0)
+            mlen = [lcp(cand[l], pos[l], 0, lm) if tabbed[l] else 0 for l in range(WAVE)]
+            stopm = [(mlen[l] >= 4 and l != 0) or flagged[l] for l in range(WAVE)]
+            special = [(mlen[l] == lm and p0 + l + lm < n) or flagged[l] for l in range(WAVE)]
+            cl = [l + mlen[l] for l in range(WAVE)]
+
+            def next_code(cc):
+                if cc >= ulim:
+                    return 64
+                j = next((x for x in range(cc, 64) if stopm[x]), None)
+                if j is None or j - cc > 32:
+                    return 65
+                return j | (128 if special[j] else 0)
+
+            nx = [next_code(cl[l]) for l in range(WAVE)]
+            lim0 = 33 - q1
+            i0 = next((x for x in range(64) if stopm[x]), 64)
+            t = (i0 | (128 if special[i0] else 0)) if (i0 <= lim0 and i0 <= 63) else 65
+            taken = []
+            while True:
+                while t < 64:
+                    taken.append(t)
+                    t = nx[t]
+                if t < 128:
+                    break
+                i = t & 63
+                L = mlen[i]
+                if flagged[i]:
+                    if stats is not None:
+                        stats["visits"] = stats.get("visits", 0) + 1
+                    # highest lower lane with the same slot that this step inserts (not strictly inside a taken copy)
+                    def inside(x):
+                        below = [y for y in taken if y < x]
+                        return bool(below) and x + 1 < cl[below[-1]]
+                    same = [x for x in range(i) if tabbed[x] and h[x] == h[i] and not inside(x)]
+                    if same:
+                        j = same[-1]
+                        L = lcp(pos[j], pos[i], 0, lm)
+                        cand[i] = p0 + j
+                        if stats is not None:
+                            stats["fwd"] = stats.get("fwd", 0) + 1
+                    if L < 4:
+                        lim_cur = cl[taken[-1]] + 32 if taken else lim0
+                        i2 = next((x for x in range(i + 1, 64) if stopm[x]), 64)
+                        t = 65 if (i2 > lim_cur or i2 > 63) else i2 | (128 if special[i2] else 0)
+                        continue
+                if L == lm and p0 + i + lm < n:
+                    L = lcp(cand[i], p0 + i, lm, n - (p0 + i))
+                mlen[i], cl[i] = L, i + L
+                taken.append(i)
+                t = next_code(i + L)
+            emit0 = next_emit
+            any_ = bool(taken)
+            last = taken[-1] if any_ else 0
+            c = cl[last]
+            ip = p0 + c
+            end_a = t == 64
+            lim = c + 32 if any_ else lim0
+            e = min(lim, ulim - 1)
+            e_final = last if end_a else e
+            fin = (ip >= ip_limit) if end_a else (ulim <= lim and ulim < 64)
+            if any_:
+                next_emit = ip
+            q1 = 0 if end_a else (e + 1 - c if any_ else q1 + e)
+            if any_:
+                s = ip + 1
+            prev_end = None
+            for l in taken:
+                records.append((emit0 if prev_end is None else p0 + prev_end, None, p0 + l - cand[l], mlen[l], p0 + l))
+                prev_end = cl[l]
+            # commit: lanes up to e_final that are not strictly inside a taken copy; the last lane of a slot wins
+            def inside_final(x):
+                below = [y for y in taken if y < x]
+                return bool(below) and x + 1 < cl[below[-1]]
+            for l in range(WAVE):
+                if l <= e_final and tabbed[l] and not inside_final(l):
+                    tab[h[l]] = pos[l]
+        # (records of dense steps carry (lit_start, -, offset, length, base): bring them to the common form)
+        records = [(r[0], r[4] - r[0], r[2], r[3]) if len(r) == 5 else r for r in records]
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
