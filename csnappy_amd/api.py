@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcsnappy.so")
+# (CSNAPPY_AMD_LIB: development only -- time a differently built library with the same tools)
+LIB_PATH = os.environ.get("CSNAPPY_AMD_LIB") or os.path.join(_HERE, "lib", "libcsnappy.so")
 
 STREAM, FRAGMENT = 0, 1
 E_OK, E_HEADER_BAD, E_OUTPUT_INSUF, E_OUTPUT_OVERRUN, E_DATA_MALFORMED = 0, -1, -2, -3, -5

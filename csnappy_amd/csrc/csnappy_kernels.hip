@@ -289,833 +289,16 @@ DEVINL uint2 pack_record(uint32_t lit_start, uint32_t base, uint32_t cnd, uint32
 	return make_uint2(base | (cnd << 16), clen | (lit_start << 16));
 }
 
-/* PART: 0 = the whole fragment; 1 = the dense placement's prologue only (*nb_out = its bucket
- * count, or kNoRecords when the fragment was handed to a later launch or needs no parsing here);
- * 2 = everything behind the prologue.  The dense kernel runs part 1 and then part 2 in the
- * instantiation that fits the fragment -- with or without the spill-over -- so that the usual
- * fragment does not pay for the spill-over's selects (1-2 % of its time, measured). */
-enum { PART_ALL = 0, PART_PROLOGUE = 1, PART_PARSE = 2 };
-
-template <bool PROF, int TAB, bool SPILL = false, int PART = PART_ALL>
-__device__ __forceinline__ void parse_fragment_body(const CompressArgs &A, uint32_t *nb_out = nullptr)
-{
-	constexpr bool GTAB = TAB == TAB_GLOBAL, DENSE = TAB == TAB_LDS_DENSE;
-	static_assert(!SPILL || DENSE, "the spill-over belongs to the dense table");
-	static_assert(PART == PART_ALL || DENSE, "only the dense placement has a prologue to split off");
-	if (PART == PART_PROLOGUE)
-		*nb_out = kNoRecords;
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const uint32_t lane = threadIdx.x;
-	const uint32_t c = blockIdx.x; /* fragment of this chunk */
-	const uint32_t blk = A.blk_base + c / A.fpb, fi = c % A.fpb;
-	const uint32_t len = A.in_len[blk];
-	const uint32_t foff = fi * kFragment;
-	if ((fi > 0 && foff >= len) || len > A.max_in_len)
-		return; /* (a block longer than the caller promised has no room in the workspace) */
-	if (A.only_unparsed) {
-		/* a later launch of the batch call: only what the earlier ones handed over */
-		const uint32_t state = A.rec_cnt[c];
-		if (state != kNoRecords && !(GTAB && state == kWantGlobal))
-			return;
-	}
-	const uint32_t n = min(len - foff, kFragment);
-	const int ws = fragment_power(n, A.p, A.mode);
-	const uint32_t shift = 33 - ws;
-	const uint8_t *src = A.in + A.in_off[blk] + foff;
-	uint2 *R = reinterpret_cast<uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
-
-	/* ---- LDS carve: table (or, TAB_GLOBAL, the occupancy bitmap) | conflict filters ----
-	 * per-fragment HBM region `tabs`: the dense ids (TAB_LDS_DENSE) or the table (TAB_GLOBAL) */
-	uint8_t *region = A.tabs + (uint64_t)c * A.tab_stride;
-	uint16_t *tab = GTAB ? reinterpret_cast<uint16_t *>(region) : reinterpret_cast<uint16_t *>(smem);
-	const uint16_t *ids = reinterpret_cast<const uint16_t *>(region);
-	/* TAB_GLOBAL: one bit per table slot, "written in this fragment".  A clear bit means the slot is
-	 * empty (the reference's zeroed table: candidate position 0) without touching memory, so the
-	 * global table is never cleared and never gathered for empty slots (41-50 % of the probes). */
-	uint32_t *occ = reinterpret_cast<uint32_t *>(smem);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
-	uint32_t *S2 = S + A.s_entries; /* second filter (present iff s_shift != 0) */
-	const uint32_t smask = A.s_entries - 1;
-
-	unsigned long long t_begin = 0, t_vec = 0, t_walk = 0, t_commit = 0, t0 = 0, t1 = 0;
-	unsigned long long n_steps = 0, n_match = 0, n_wide = 0, n_sparse = 0;
-	unsigned long long t_chain = 0, t_stop = 0, t_place = 0, t_rec = 0, tq = 0, t_pre = 0, t_loop_end = 0;
-	unsigned long long tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
-	unsigned long long n_hops = 0, n_flagv = 0, n_fwd = 0, n_flagged = 0;
-	if (PROF)
-		t_begin = __builtin_amdgcn_s_memtime();
-
-	/* SPILL: buckets dense_cap.. of the fragment live in a small table in HBM behind its ids.
-	 * Fragments just over the LDS table's size -- URL lists sit at 4.3-5.5 k buckets -- are parsed
-	 * in the same launch with the same LDS geometry (16 per CU) this way, their few high buckets
-	 * costing a global gather per step, instead of all over again in a second launch with a larger
-	 * LDS table and 10 fragments per CU.  (Compiled into every fragment's parser, the selects cost
-	 * 1-2 % on text and 2-5 % on pages: the dense kernel holds both parsers and picks per fragment.) */
-	uint16_t *spill = reinterpret_cast<uint16_t *>(region + A.spill_off);
-
-	if (PART == PART_PROLOGUE && n < kMargin) {
-		*nb_out = 0; /* no prologue, no spill-over: part 2 writes the one literal */
-		return;
-	}
-	if (n >= kMargin) {
-		if (DENSE && PART != PART_PARSE) {
-			/* ---- prologue: dense bucket ids (see the header comment) ----
-			 * seen1/seen2: slot hit at least once / at least twice; pref: buckets below a word */
-			const uint32_t nwords = (1u << (ws - 1)) >> 5; /* >= 8 */
-			uint32_t *seen1 = reinterpret_cast<uint32_t *>(smem), *seen2 = seen1 + nwords;
-			if (A.sample_min && n == kFragment) {
-				/* Placement by a cheap look at the data (a speed heuristic, the bytes do not depend
-				 * on it): fragments made of long runs need few steps, and the fixed cost of this
-				 * prologue would be most of their time -- the global-table launch (no prologue,
-				 * more fragments per CU) is faster for them.  Hash every 16th position into an
-				 * 8192-bit map; few distinct values = repetitive. */
-				for (uint32_t k = lane; k < 256; k += 64)
-					seen1[k] = 0;
-				wave_lds_fence();
-				for (uint32_t j = 0; j < 32; ++j) {
-					uint32_t w;
-					__builtin_memcpy(&w, src + 16 * lane + 1024 * j, 4);
-					const uint32_t h = (w * kHashMul) >> 19;
-					atomicOr(&seen1[h >> 5], 1u << (h & 31));
-				}
-				wave_lds_fence();
-				uint32_t d = 0, distinct;
-				for (uint32_t k = 0; k < 4; ++k)
-					d += (uint32_t)__builtin_popcount(seen1[lane * 4 + k]);
-				(void)wave_excl_scan(d, lane, &distinct);
-				wave_lds_fence();
-				if (distinct < A.sample_min) {
-					if (lane == 0)
-						A.rec_cnt[c] = kWantGlobal;
-					return;
-				}
-			}
-			uint16_t *pref = reinterpret_cast<uint16_t *>(seen2 + nwords);
-			for (uint32_t k = lane; k < 2 * nwords; k += 64)
-				seen1[k] = 0;
-			wave_lds_fence();
-			const uint32_t npos = n - 3; /* positions that have four bytes */
-			/* eight consecutive positions per lane and iteration: the 16 bytes at i cover their
-			 * hashes; the next iteration's bytes are requested before this one's are used */
-			auto load16 = [&](uint32_t i) -> uint4 {
-				uint4 v = make_uint4(0, 0, 0, 0);
-				if (i + 16 <= n) {
-					__builtin_memcpy(&v, src + i, 16);
-				} else if (i < n) {
-					uint32_t w[4] = { 0, 0, 0, 0 };
-					for (uint32_t k = 0; i + k < n; ++k)
-						w[k >> 2] |= (uint32_t)src[i + k] << (8 * (k & 3));
-					v = make_uint4(w[0], w[1], w[2], w[3]);
-				}
-				return v;
-			};
-			auto hash8 = [&](const uint4 &v, uint32_t hh[8]) {
-				const uint32_t w0 = v.x, w1 = v.y, w2 = v.z;
-				hh[0] = (w0 * kHashMul) >> shift;
-				hh[1] = (__builtin_amdgcn_alignbyte(w1, w0, 1) * kHashMul) >> shift;
-				hh[2] = (__builtin_amdgcn_alignbyte(w1, w0, 2) * kHashMul) >> shift;
-				hh[3] = (__builtin_amdgcn_alignbyte(w1, w0, 3) * kHashMul) >> shift;
-				hh[4] = (w1 * kHashMul) >> shift;
-				hh[5] = (__builtin_amdgcn_alignbyte(w2, w1, 1) * kHashMul) >> shift;
-				hh[6] = (__builtin_amdgcn_alignbyte(w2, w1, 2) * kHashMul) >> shift;
-				hh[7] = (__builtin_amdgcn_alignbyte(w2, w1, 3) * kHashMul) >> shift;
-			};
-			/* a sweep over all positions: 2048 per iteration (four 16-byte loads per lane in flight,
-			 * the next iteration's requested before this one's are used) */
-			auto sweep = [&](auto &&body) {
-				uint4 nxt[4];
-#pragma unroll
-				for (uint32_t j = 0; j < 4; ++j)
-					nxt[j] = load16(512 * j + 8 * lane);
-				for (uint32_t b0 = 0; b0 < npos; b0 += 2048) {
-					uint4 cur[4];
-#pragma unroll
-					for (uint32_t j = 0; j < 4; ++j) {
-						cur[j] = nxt[j];
-						if (b0 + 2048 < npos)
-							nxt[j] = load16(b0 + 2048 + 512 * j + 8 * lane);
-					}
-#pragma unroll
-					for (uint32_t j = 0; j < 4; ++j) {
-						const uint32_t i = b0 + 512 * j + 8 * lane;
-						if (b0 + 512 * j < npos)
-							body(cur[j], i, i < npos ? min(8u, npos - i) : 0u);
-					}
-				}
-			};
-			sweep([&](const uint4 &v, uint32_t, uint32_t cntp) {
-				uint32_t hh[8], old[8];
-				hash8(v, hh);
-#pragma unroll
-				for (uint32_t k = 0; k < 8; ++k)
-					old[k] = k < cntp ? atomicOr(&seen1[hh[k] >> 5], 1u << (hh[k] & 31)) : 0u;
-#pragma unroll
-				for (uint32_t k = 0; k < 8; ++k)
-					if (k < cntp && ((old[k] >> (hh[k] & 31)) & 1u))
-						atomicOr(&seen2[hh[k] >> 5], 1u << (hh[k] & 31));
-			});
-			wave_lds_fence();
-			if (PROF)
-				tp1 = __builtin_amdgcn_s_memtime();
-			const uint32_t per = max(1u, nwords >> 6);
-			uint32_t mine = 0;
-			for (uint32_t k = 0; k < per; ++k) {
-				const uint32_t w = lane * per + k;
-				if (w < nwords)
-					mine += (uint32_t)__builtin_popcount(seen2[w]);
-			}
-			uint32_t nb;
-			uint32_t run = wave_excl_scan(mine, lane, &nb);
-			if (nb > A.dense_cap + ((SPILL || PART == PART_PROLOGUE) ? A.spill_cap : 0u)) {
-				/* more buckets than the LDS table (and its spill-over) hold: a later launch takes it */
-				if (lane == 0)
-					A.rec_cnt[c] = kNoRecords;
-				return;
-			}
-			for (uint32_t k = 0; k < per; ++k) {
-				const uint32_t w = lane * per + k;
-				if (w < nwords) {
-					pref[w] = (uint16_t)run;
-					run += (uint32_t)__builtin_popcount(seen2[w]);
-				}
-			}
-			wave_lds_fence();
-			if (PROF)
-				tp2 = __builtin_amdgcn_s_memtime();
-			uint16_t *wids = reinterpret_cast<uint16_t *>(region);
-			sweep([&](const uint4 &v, uint32_t i, uint32_t cntp) {
-				uint32_t hh[8], id[8];
-				hash8(v, hh);
-#pragma unroll
-				for (uint32_t k = 0; k < 8; ++k) {
-					const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
-					const uint32_t b = 1u << (hh[k] & 31);
-					id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
-				}
-				if (cntp == 8) {
-					*reinterpret_cast<uint4 *>(wids + i) =
-						make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
-							   id[6] | (id[7] << 16));
-				} else {
-#pragma unroll
-					for (uint32_t k = 0; k < 7; ++k)
-						if (k < cntp)
-							wids[i + k] = (uint16_t)id[k];
-				}
-			});
-			if (SPILL || (PART == PART_PROLOGUE && nb > A.dense_cap)) {
-				uint4 *z = reinterpret_cast<uint4 *>(spill);
-				for (uint32_t k = lane; k < (A.spill_cap * 2 + 15) / 16; k += 64)
-					z[k] = make_uint4(0, 0, 0, 0);
-			}
-			wave_lds_fence();
-			/* the ids (and the zeroed spill table) are read back by this wave only (same CU, same
-			 * L1/L2 path, program order); make the stores leave the wave before the first load of
-			 * them is issued */
-			if (PROF)
-				tp3 = __builtin_amdgcn_s_memtime();
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (PROF)
-				tp4 = __builtin_amdgcn_s_memtime();
-			if (PART == PART_PROLOGUE) {
-				*nb_out = nb;
-				return;
-			}
-		}
-		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
-		{
-			const uint32_t zb = GTAB ? (1u << ws) >> 4 : DENSE ? 2 * A.dense_cap : 1u << ws;
-			uint4 *z4 = reinterpret_cast<uint4 *>(smem);
-			for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
-				z4[k] = make_uint4(0, 0, 0, 0);
-			uint4 *s4 = reinterpret_cast<uint4 *>(S);
-			for (uint32_t k = lane; k < (((A.s_shift ? 2 : 1) * A.s_entries) >> 2); k += 64)
-				s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-		}
-		wave_lds_fence();
-	}
-
-	/* ================================== PARSER ================================== */
-	uint32_t nev = 0;       /* records written */
-	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
-	const uint64_t lt_mask = (1ull << lane) - 1;
-
-	/* one record produced by uniform code: {literal [lit_start, base), copy(base - cnd, clen)} */
-	auto add_record = [&](uint32_t lit_start, uint32_t base, uint32_t cnd, uint32_t clen) {
-		if (lane == 0)
-			R[nev] = pack_record(lit_start, base, cnd, clen);
-		++nev;
-	};
-	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
-	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
-		const uint32_t ma = cnd + kLocalMatch, mb = base + kLocalMatch, lim = n - mb;
-		uint32_t done = 0;
-		for (;;) {
-			const uint32_t o = done + lane * 8;
-			uint32_t m8 = 0;
-			bool term = true;
-			if (o < lim) {
-				/* the last few bytes of the fragment: never read past the input -- take the eight
-				 * bytes that END at the fragment's end and drop the ones in front of o */
-				const uint32_t r = min(8u, lim - o), back = 8 - r;
-				uint64_t xa, xb;
-				__builtin_memcpy(&xa, src + ma + o - back, 8);
-				__builtin_memcpy(&xb, src + mb + o - back, 8);
-				const uint64_t x = (xa ^ xb) >> (8 * back);
-				const uint32_t z = (uint32_t)__ffsll((unsigned long long)x); /* 0 when x == 0 */
-				m8 = z ? min((z - 1) >> 3, r) : r;
-				term = m8 < 8 || o + 8 >= lim;
-			}
-			const uint64_t tmask = ballot64(term);
-			if (tmask) {
-				const uint32_t t = first_lane(tmask);
-				return done + 8 * t + rdlane(m8, t);
-			}
-			done += 512;
-		}
-	};
-
-	/* (a 15-byte fragment has ip_limit 0: no probe ever happens, it is one literal like n < 15) */
-	if (n > kMargin) {
-		const uint32_t ip_limit = n - kMargin;
-		uint32_t ip = 0;        /* position right after the last copy (spec > 0) */
-		uint32_t spec = 0;      /* leading special lanes: 2 = {insert ip-1, probe ip}, 1 = {probe ip} */
-		uint32_t s = 1, qi = 0; /* scan start and index of the next scan probe */
-		uint32_t epoch = 0x03ffffffu;
-		bool fin = false;
-		uint32_t first4;
-		__builtin_memcpy(&first4, src, 4);
-		const uint32_t chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
-
-		/* lane positions of a step; the 16 bytes at the lane's position (and its bucket id) are
-		 * fetched one step ahead, as soon as the cursor of the next step is known, to take that
-		 * round trip off the dependent chain */
-		bool sparse;
-		uint32_t p0, pos;
-		bool valid;
-		uint32_t raw[4], sid = kNoBucket;
-		auto place = [&]() {
-			sparse = spec == 0 && qi >= 32;
-			p0 = spec == 2 ? ip - 1 : spec == 1 ? ip : s + qi;
-			if (sparse) {
-				pos = scan_pos(s, qi + lane);
-				/* csnappy_compress.c:542-544: a probe happens only if the NEXT position is
-				 * still <= ip_limit */
-				valid = scan_pos(s, qi + lane + 1) <= ip_limit;
-			} else {
-				pos = p0 + lane;
-				valid = pos + 1 <= ip_limit; /* stride-1 probes, the re-match probe and the insert */
-			}
-			if (!valid)
-				pos = 0;
-			/* valid lanes have 16 bytes of fragment at pos (pos <= n - 16); the others read position
-			 * 0 (n >= 16 here).  No branch on `valid`: a lane-divergent branch next to the joins of
-			 * the cursor state makes the compiler treat that state as divergent and the whole
-			 * chain walk leaves the scalar unit */
-			uint4 v;
-			__builtin_memcpy(&v, src + pos, 16);
-			const uint16_t idv = DENSE ? ids[pos] : (uint16_t)kNoBucket;
-			raw[0] = v.x;
-			raw[1] = v.y;
-			raw[2] = v.z;
-			raw[3] = v.w;
-			sid = idv;
-		};
-		place();
-		if (PROF)
-			t_pre = __builtin_amdgcn_s_memtime() - t_begin;
-
-		while (!fin) {
-			if (PROF) {
-				t0 = __builtin_amdgcn_s_memtime();
-				n_steps++;
-				if (sparse)
-					n_sparse++;
-			}
-			/* this step's lane state (the next step's is placed before the step ends) */
-			const bool sparse_c = sparse;
-			const uint32_t p0_c = p0, pos_c = pos;
-			const bool valid_c = valid;
-			uint32_t cb[4];
-			const uint32_t me0 = raw[0], me1 = raw[1], me2 = raw[2], me3 = raw[3];
-			const uint32_t prod = me0 * kHashMul;
-			/* slot = what identifies the lane's table entry: the dense bucket id or the hash */
-			const uint32_t slot = DENSE ? sid : prod >> shift;
-			/* lanes that take part in the table at all (a lone position's slot is never read) */
-			const bool tabbed = DENSE ? valid_c && slot != kNoBucket : valid_c;
-			/* The uint16 table entries hold 15-bit positions; bit 15 carries one more bit of the
-			 * hash product of the bytes at that position.  Equal 4 bytes imply equal products,
-			 * so a candidate whose check bit differs cannot match and its bytes need not be
-			 * fetched (an empty slot stands for position 0: its check bit is that of F[0..4)). */
-			const uint32_t chk = (prod >> (shift - 1)) & 1u;
-			/* slot sharing inside a step is detected with one or two small filters keyed by
-			 * different bits of the slot: a lane is flagged only if BOTH report an earlier lane
-			 * (two lanes with the same slot collide in both; a false alarm needs two
-			 * independent key collisions) */
-			const uint32_t key = slot & smask;
-			const uint32_t key2 = DENSE ? ((slot >> A.s_shift) ^ (slot << (A.s_shift - 5))) & smask
-						    : (slot >> A.s_shift) & smask;
-			/* (no branch on `tabbed`: a lane that takes no part offers the largest value) */
-			const uint32_t ftag = tabbed ? (epoch << 6) | lane : ~0u;
-			const bool two_filters = DENSE || A.s_shift != 0; /* (dense: always two) */
-			atomicMin(&S[key], ftag);
-			if (two_filters)
-				atomicMin(&S2[key2], ftag);
-			/* A lane that shares its slot with an earlier lane of the step ("flagged") cannot trust
-			 * the table: sparse steps are cut in front of the first such lane; dense steps keep
-			 * going and resolve the lane when the chain arrives at it (see the chain loop). */
-			uint32_t cand = 0, first_same;
-			/* (SPILL) my bucket is one of the few beyond the LDS table */
-			const bool spilled = SPILL && tabbed && slot >= A.dense_cap;
-			if (!GTAB) {
-				const bool in_lds = tabbed && !spilled;
-				cand = tab[in_lds ? slot : 0u];
-				cand = in_lds ? cand : 0u;
-			}
-			if (SPILL && ballot64(spilled)) {
-				const uint32_t g = spill[spilled ? slot - A.dense_cap : 0u];
-				cand = spilled ? g : cand;
-			}
-			wave_lds_fence();
-			first_same = S[key] & 63u; /* lowest lane with my slot key */
-			if (two_filters)
-				first_same = max(first_same, S2[key2] & 63u);
-			const bool flagged = tabbed && first_same < lane;
-			uint64_t cmask = ballot64(flagged); /* flagged lanes */
-			const uint64_t imask = ~ballot64(valid_c);
-			const int c1 = cmask ? (int)first_lane(cmask) : 64; /* first lane that depends on an earlier one */
-			const int v = imask ? (int)first_lane(imask) : 64;  /* first lane past the scan limit */
-			int ulim = sparse_c ? min(c1, v) : v;
-			/* TAB_GLOBAL: the table gathers go to L2/HBM, so flagged lanes, lanes behind a cut and
-			 * empty slots do not gather at all */
-			if (GTAB && (int)lane < ulim && !flagged && ((occ[slot >> 5] >> (slot & 31)) & 1u))
-				cand = tab[slot];
-			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
-			cand &= 0x7fffu;
-			/* the 16 bytes at the candidate (cand < pos: inside the fragment); lanes without one
-			 * read position 0 -- one broadcast line, cheaper than masking the load off */
-			const bool gathered = (int)lane < ulim && maybe && !(GTAB && flagged);
-			{
-				uint4 w4;
-				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
-				cb[0] = w4.x;
-				cb[1] = w4.y;
-				cb[2] = w4.z;
-				cb[3] = w4.w;
-			}
-			/* lane-local match length, capped at kLocalMatch (the end of the fragment is at least
-			 * 16 bytes away from every valid probe position) */
-			const uint64_t xlo = ((uint64_t)(me1 ^ cb[1]) << 32) | (me0 ^ cb[0]);
-			const uint64_t xhi = ((uint64_t)(me3 ^ cb[3]) << 32) | (me2 ^ cb[2]);
-			uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
-			const uint64_t matchmask = ballot64((int)lane < ulim && mlen >= 4);
-			epoch--;
-			if (PROF) {
-				t1 = __builtin_amdgcn_s_memtime();
-				t_vec += t1 - t0;
-			}
-
-			int e_final = 0;        /* last lane whose table write is committed */
-			bool inside = false;    /* dense: this lane lies strictly inside a taken copy */
-			uint64_t taken = 0;     /* dense: lanes whose match is part of the chain */
-			uint32_t cl = lane + mlen; /* dense: lane of the re-match probe after my match */
-			const uint32_t emit0 = next_emit;
-			const uint32_t nev0 = nev;
-			uint2 rec = make_uint2(0, 0);
-			bool rec_mine = false;
-			uint32_t rec_idx = 0;
-			bool wide_rec = false;
-			uint32_t emit1 = 0, wbase_l = 0, wcnd = 0;
-			if (sparse_c) {
-				/* ---- sparse step: ends at its first match ---- */
-				if (matchmask == 0) {
-					e_final = ulim - 1;
-					if (ulim == v && v < 64)
-						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
-					else
-						qi += (uint32_t)ulim;
-				} else {
-					const int i = (int)first_lane(matchmask);
-					e_final = i;
-					const uint32_t base = rdlane(pos_c, i), cnd = rdlane(cand, i);
-					uint32_t L = rdlane(mlen, i);
-					if (PROF)
-						n_match++;
-					if (L == kLocalMatch && base + L < n)
-						L += extend(cnd, base);
-					add_record(next_emit, base, cnd, L);
-					ip = base + L;
-					next_emit = ip;
-					if (ip >= ip_limit)
-						fin = true; /* :585-586 */
-					spec = 2;
-				}
-				if (!fin)
-					place();
-			} else {
-				/* ---- dense step ----
-				 * nx = the next match lane of the chain if my match is taken:
-				 *      64 -> the re-match probe falls outside the usable lanes (step ends, spec 2)
-				 *      65 -> none of the 33 probes after my match (re-match + 32 scan) matches */
-				/* flagged lanes are stops of the chain like matches: what they hold is decided
-				 * when (and if) the chain gets there */
-				const uint64_t flagmask = ulim < 64 ? cmask & ((1ull << ulim) - 1) : cmask;
-				if (PROF)
-					n_flagged += __builtin_popcountll(flagmask);
-				const uint64_t stopmask = matchmask | flagmask;
-				const uint64_t widemask = ballot64(mlen == kLocalMatch && p0_c + lane + kLocalMatch < n);
-				const uint64_t special = widemask | flagmask; /* stops that are not plain matches */
-				uint32_t nx; /* ... | 128 when that next stop is a special lane */
-				{
-					const uint64_t rest = cl < 64 ? stopmask >> cl : 0;
-					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-					const uint32_t j = cl + fm;
-					const bool in = (fm <= 32 && j <= 63);
-					const uint32_t sp = in ? (uint32_t)(special >> j) & 1u : 0u;
-					nx = (int)cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
-				}
-				int a, zl;      /* first lane that may probe, lane of scan index 0 */
-				uint32_t seg_s; /* scan start of the current segment */
-				if (spec == 2) {
-					a = 1;
-					zl = 2;
-					seg_s = ip + 1;
-				} else if (spec == 1) {
-					a = 0;
-					zl = 1;
-					seg_s = ip + 1;
-				} else {
-					a = 0;
-					zl = -(int)qi;
-					seg_s = s;
-				}
-				int lim = zl + 31; /* last lane whose probe is still one of the 32 stride-1 probes */
-				const uint64_t m0 = stopmask & ((~0ull) << a);
-				int i = m0 ? (int)first_lane(m0) : 64;
-				int last = -1;
-				uint32_t stop = 67; /* 67: no match in the first segment, 66: wide match at lane i */
-				uint32_t wide_len = 0;
-				/* the same as nx for one match on the scalar unit: c = lane behind it */
-				auto scalar_next = [&](int cc) -> uint32_t {
-					if (cc >= ulim)
-						return 64u;
-					const uint64_t rest = stopmask >> cc;
-					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-					const uint32_t j = (uint32_t)cc + fm;
-					if (fm > 32 || j > 63)
-						return 65u;
-					return j | (((uint32_t)(special >> j) & 1u) << 7);
-				};
-				if (i <= lim && i <= 63) {
-					bool sp = (special >> i) & 1;
-					for (;;) {
-						uint32_t t;
-						if (sp) {
-							uint32_t L = kLocalMatch;
-							if ((flagmask >> i) & 1) {
-								if (PROF)
-									n_flagv++;
-								/* ---- the chain probes a flagged lane ----
-								 * Its candidate is the latest position inserted for its slot: the
-								 * highest lane below it that this step inserts (not strictly inside a
-								 * copy of the chain) and that has the same slot -- whose bytes are
-								 * that lane's own 16 bytes -- else the table value.  (The global
-								 * placement did not gather the latter: cut the step here.) */
-								const uint64_t below = taken & lt_mask;
-								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-								const uint64_t ins = ((1ull << i) - 1) & ~ballot64(below != 0 && lane + 1 < cprev);
-								const uint32_t slot_i = rdlane(slot, i);
-								const uint64_t same = ballot64(tabbed & (slot == slot_i)) & ins;
-								if (same) {
-									if (PROF)
-										n_fwd++;
-									const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
-									const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
-									const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
-									const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
-									const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
-									const uint32_t ml = common_prefix16(ylo, yhi);
-									L = rdlane(ml, i);
-									if ((int)lane == i) {
-										cand = p0_c + j;
-										mlen = ml;
-									}
-								} else if (GTAB) {
-									ulim = i;
-									stop = last < 0 ? 67u : (int)rdlane(cl, last) >= i ? 64u : 65u;
-									break;
-								} else {
-									L = rdlane(mlen, i);
-								}
-								if (L < 4) {
-									/* no match: on to the next stop of the current segment */
-									const int lim_cur = last >= 0 ? (int)rdlane(cl, last) + 32 : lim;
-									const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
-									const int i2 = m ? (int)first_lane(m) : 64;
-									if (i2 > lim_cur || i2 > 63) {
-										stop = last >= 0 ? 65u : 67u;
-										break;
-									}
-									i = i2;
-									sp = (special >> i) & 1;
-									continue;
-								}
-							}
-							if (L == kLocalMatch && p0_c + (uint32_t)i + kLocalMatch < n) {
-								/* a match longer than the lane-local cap: extend it wave-wide.  If it
-								 * still ends inside the usable lanes it is a link of the chain like
-								 * any other; else it ends the step. */
-								L = wide_len = kLocalMatch + extend(rdlane(cand, i), p0_c + (uint32_t)i);
-								if (PROF)
-									n_wide++;
-								if (i + (int)L >= ulim) {
-									stop = 66;
-									break;
-								}
-							}
-							if ((int)lane == i) {
-								mlen = L;
-								cl = lane + L;
-							}
-							taken |= 1ull << i;
-							last = i;
-							t = scalar_next(i + (int)L);
-						} else {
-							/* plain matches: hop from match to match */
-							for (;;) {
-								if (PROF)
-									n_hops++;
-								asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */
-								last = i;
-								t = rdlane(nx, i);
-								if (t >= 64)
-									break;
-								i = (int)t;
-							}
-						}
-						if (t < 64) {
-							i = (int)t;
-							sp = false;
-							continue;
-						}
-						if (t < 128) {
-							stop = t; /* 64 / 65 */
-							break;
-						}
-						i = (int)(t & 63);
-						sp = true;
-					}
-				}
-				if (PROF) {
-					tq = __builtin_amdgcn_s_memtime();
-					t_chain += tq - t1;
-				}
-				if (last >= 0) {
-					const int c_last = (int)rdlane(cl, last);
-					ip = p0_c + (uint32_t)c_last;
-					next_emit = ip;
-					a = c_last;
-					zl = c_last + 1;
-					lim = c_last + 32;
-					seg_s = ip + 1;
-					if (PROF)
-						n_match += __builtin_popcountll(taken);
-				}
-				if (stop == 66) {
-					/* the extended match runs past the usable lanes: it ends the step */
-					wbase_l = p0_c + (uint32_t)i;
-					wcnd = rdlane(cand, i);
-					const uint32_t L = wide_len;
-					e_final = i;
-					ip = wbase_l + L;
-					if (PROF)
-						n_match++;
-					spec = 2;
-					if (ip >= ip_limit)
-						fin = true;
-				} else if (stop == 64) {
-					e_final = last;
-					spec = 2;
-					if (ip >= ip_limit)
-						fin = true; /* :585-586 */
-				} else {
-					/* 65 / 67: the current segment (a, zl, lim, seg_s) has no match */
-					const int e = min(lim, ulim - 1);
-					e_final = e;
-					if (ulim == v && v <= lim && v < 64) {
-						fin = true; /* next probe is past ip_limit: goto emit_remainder */
-					} else if (e < a) {
-						spec = 1; /* only the ip-1 insert was usable; the re-match probe is next */
-						e_final = 0;
-					} else {
-						spec = 0;
-						s = seg_s;
-						qi = (uint32_t)(e + 1 - zl);
-					}
-				}
-				emit1 = next_emit; /* literal start of a wide record */
-				if (stop == 66) {
-					next_emit = ip;
-					wide_rec = true;
-				}
-				if (PROF) {
-					const unsigned long long t = __builtin_amdgcn_s_memtime();
-					t_stop += t - tq;
-					tq = t;
-				}
-				/* the cursor of the next step is known: fetch its bytes now */
-				if (!fin)
-					place();
-				if (PROF) {
-					const unsigned long long t = __builtin_amdgcn_s_memtime();
-					t_place += t - tq;
-					tq = t;
-				}
-
-				/* ---- records of the taken matches, built by their own lanes ---- */
-				if (taken) {
-					const uint64_t below = taken & lt_mask;
-					const bool hasprev = below != 0;
-					const uint32_t jprev = hasprev ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-					const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-					rec_mine = (taken >> lane) & 1;
-					const uint32_t lit_start = hasprev ? p0_c + cprev : emit0;
-					inside = hasprev && lane + 1 < cprev; /* strictly inside a taken copy: never inserted */
-					rec_idx = nev0 + (uint32_t)__builtin_popcountll(below);
-					rec = pack_record(lit_start, p0_c + lane, cand, mlen);
-					nev = nev0 + (uint32_t)__builtin_popcountll(taken);
-				}
-				if (PROF)
-					t_rec += __builtin_amdgcn_s_memtime() - tq;
-			}
-			if (PROF) {
-				t0 = __builtin_amdgcn_s_memtime();
-				t_walk += t0 - t1;
-			}
-			/* The next step's own bytes (requested by place() above) are waited for HERE, in front
-			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
-			 * behind the stores (at the loop's back edge, where the compiler would put it) also sits
-			 * out the stores' round trip -- once per step, on the dependent chain. */
-			asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(sid));
-			if (rec_mine)
-				R[rec_idx] = rec;
-			if (wide_rec)
-				add_record(emit1, wbase_l, wcnd, ip - wbase_l);
-			/* commit table[slot] = position for every lane that was probed or inserted
-			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
-			bool commit = (int)lane <= e_final && !inside && tabbed;
-			{
-				/* of several committed lanes with one slot only the last may write (flagged lanes
-				 * that the chain inserted; sparse steps never commit one) */
-				const uint64_t cm = ballot64(commit);
-				uint64_t fl = cmask & cm;
-				uint64_t dead = 0;
-				while (fl) {
-					/* one round per shared slot, highest lane first (runs: one slot on most lanes) */
-					const uint32_t x = 63u - (uint32_t)__builtin_clzll(fl);
-					const uint64_t same = ballot64(slot == rdlane(slot, x)) & cm;
-					dead |= same & ((1ull << x) - 1);
-					fl &= ~same;
-				}
-				if ((dead >> lane) & 1)
-					commit = false;
-			}
-			if (commit && !spilled) {
-				tab[slot] = (uint16_t)(pos_c | (chk << 15));
-				if (GTAB)
-					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
-			}
-			if (SPILL && commit && spilled)
-				spill[slot - A.dense_cap] = (uint16_t)(pos_c | (chk << 15));
-			wave_lds_fence();
-			if (PROF)
-				t_commit += __builtin_amdgcn_s_memtime() - t0;
-		}
-	}
-
-	if (PROF)
-		t_loop_end = __builtin_amdgcn_s_memtime();
-	/* emit_remainder, csnappy_compress.c:600-605: literal [next_emit, n), no copy */
-	if (next_emit < n)
-		add_record(next_emit, n, n, 0);
-	if (lane == 0)
-		A.rec_cnt[c] = nev;
-	if (PROF && lane == 0) {
-		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-		atomicAdd(&A.prof[0], t_end - t_begin);
-		atomicAdd(&A.prof[1], t_vec);
-		atomicAdd(&A.prof[2], t_walk);
-		atomicAdd(&A.prof[3], t_commit);
-		atomicAdd(&A.prof[5], n_steps);
-		atomicAdd(&A.prof[6], n_match);
-		atomicAdd(&A.prof[7], n_wide);
-		atomicAdd(&A.prof[8], n_sparse);
-		atomicAdd(&A.prof[9], 1ull);
-		atomicAdd(&A.prof[10], t_chain);
-		atomicAdd(&A.prof[11], t_stop);
-		atomicAdd(&A.prof[12], t_place);
-		atomicAdd(&A.prof[13], t_rec);
-		atomicAdd(&A.prof[14], t_pre);
-		atomicAdd(&A.prof[15], t_end - t_loop_end);
-		atomicAdd(&A.prof[16], tp1 - t_begin);
-		atomicAdd(&A.prof[17], tp2 - tp1);
-		atomicAdd(&A.prof[18], tp3 - tp2);
-		atomicAdd(&A.prof[19], tp4 - tp3);
-		atomicAdd(&A.prof[20], n_hops);
-		atomicAdd(&A.prof[21], n_flagv);
-		atomicAdd(&A.prof[22], n_fwd);
-		atomicAdd(&A.prof[23], n_flagged);
-	}
-}
-
-/* table indexed by the hash, in LDS (tables of <= 8 KiB) */
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments(CompressArgs A)
-{
-	parse_fragment_body<false, TAB_LDS_HASH>(A);
-}
-
-/* table indexed by dense bucket ids, in LDS (the default for tables that would not fit) */
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense(CompressArgs A)
-{
-	uint32_t nb;
-	parse_fragment_body<false, TAB_LDS_DENSE, false, PART_PROLOGUE>(A, &nb);
-	if (nb == kNoRecords)
-		return;
-	/* a few buckets more than the LDS table holds: those few live in HBM (URL lists) */
-	if (nb > A.dense_cap)
-		parse_fragment_body<false, TAB_LDS_DENSE, true, PART_PARSE>(A);
-	else
-		parse_fragment_body<false, TAB_LDS_DENSE, false, PART_PARSE>(A);
-}
-
-/* ... without a spill-over (pages: the second launch's table holds any page, and re-reading the
- * descriptors between the two parts is 2.5 % of a page's time) */
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_whole(CompressArgs A)
-{
-	parse_fragment_body<false, TAB_LDS_DENSE>(A);
-}
-
-/* full table in global memory (fragments with more buckets than the dense LDS table holds) */
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(CompressArgs A)
-{
-	parse_fragment_body<false, TAB_GLOBAL>(A);
-}
-
 /* ==========================================================================================
- * The lean parser (round 3).  Same step logic as parse_fragment_body above -- dense and sparse
- * steps, flagged lanes, wave-wide extension -- written for the scalar unit: one CU has ONE scalar
- * ALU for its 16 resident parser waves and the round-2 loop spent 230 scalar instructions per
- * 64-position step there (profiles/r03a_text_p16_instmix.txt), more than the vector units'
- * share.  What changed:
+ * The step loop (round 3; round 2's, with three cursor cases and a per-hop state machine, spent
+ * 230 scalar instructions per 64-position step on the CU's ONE scalar unit):
  *   - one cursor form.  The state between steps is (s, q1): the scan that starts at position s
  *     has made q1 - 1 probes; q1 == 0 says "a copy just ended at ip = s - 1: insert ip - 1,
  *     probe ip" (csnappy_compress.c:585-594), and that re-match probe is simply scan index -1
  *     (33 stride-1 probes follow a copy, 32 the start of the fragment, :535-552).  Lane 0 of a
  *     dense step is ALWAYS an insert-only lane -- ip - 1 after a copy, otherwise the last position
- *     the previous step probed, whose re-insertion changes nothing -- so the spec = 0/1/2 cases
- *     and their joins are gone.
- *   - ulim (lanes in front of the scan limit) is arithmetic, not a ballot.
+ *     the previous step probed, whose re-insertion changes nothing.
+ *   - the lanes in front of the scan limit are arithmetic, not a ballot.
  *   - the chain loop has one exit code; the last copy and the window it leaves are derived from
  *     the `taken` mask after the walk instead of being tracked through it; a wide match that
  *     leaves the step is a link of the chain like any other (its own lane writes its record).
@@ -1123,7 +306,7 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(
  *     the insert mask is only built when there is one.
  *   - block descriptors are read once, before the prologue's stores, so they stay scalar loads.
  * ======================================================================================== */
-/* Conflict filters of the lean / wide parsers.  A lane whose slot is also the slot of a LOWER lane
+/* Conflict filters.  A lane whose slot is also the slot of a LOWER lane
  * of the step cannot trust its table read ("flagged").  Two small arrays in LDS, keyed by different
  * bits of the slot, receive with atomicMin a tag {epoch, slot, lane}; the epoch counts down, so
  * tags of earlier steps never win and nothing is cleared between steps.  Within a step the
@@ -1132,18 +315,23 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(
  * second array takes the slots in reverse order, so it settles the lanes with the largest slot
  * of a key.  A lane that neither array settles (a smaller slot shares its first key AND a larger
  * one its second) is flagged to be safe.  (Round 2 compared lane numbers only: every collision of
- * two keys was a false alarm -- 3.4 lanes per 64-position step of text, 16 per 128.) */
-constexpr uint32_t kFilterSlots = 8191;  /* slots are < 8192: dense ids, or hashes of tables <= 8 KiB x 2 */
-constexpr uint32_t kFilterEpochs = 4095; /* steps between two clearings of the filters */
+ * two keys was a false alarm -- 3.4 lanes per 64-position step of text.) */
+/* SB = bits of a slot: 13 for dense ids, 15 for hashes (the full table in global memory, or in
+ * LDS); the epoch gets what is left of 32 bits beside them and 7 bits of lane */
+template <int SB> struct FilterTag {
+	static constexpr uint32_t kSlots = (1u << SB) - 1;         /* largest slot */
+	static constexpr uint32_t kEpochs = (1u << (25 - SB)) - 1; /* steps between two clearings of the filters */
+	static DEVINL uint32_t tag(uint32_t epoch, uint32_t slot_field, uint32_t vlane, bool tabbed)
+	{
+		return tabbed ? (epoch << (7 + SB)) | (slot_field << 7) | vlane : ~0u;
+	}
+	/* e1, e2: what the two arrays hold for my keys after the step's atomics (e2 = ~0: one array only) */
+	static DEVINL bool flags(uint32_t e1, uint32_t e2, uint32_t slot, uint32_t vlane);
+};
 
-DEVINL uint32_t filter_tag(uint32_t epoch, uint32_t slot_field, uint32_t vlane, bool tabbed)
+template <int SB> DEVINL bool FilterTag<SB>::flags(uint32_t e1, uint32_t e2, uint32_t slot, uint32_t vlane)
 {
-	return tabbed ? (epoch << 20) | (slot_field << 7) | vlane : ~0u;
-}
-
-/* e1, e2: what the two arrays hold for my keys after the step's atomics (e2 = ~0: one array only) */
-DEVINL bool filter_flags(uint32_t e1, uint32_t e2, uint32_t slot, uint32_t vlane)
-{
+	constexpr uint32_t kFilterSlots = kSlots;
 	/* (bitwise, not short-circuit: with branches the compiler reads the second array only after it
 	 * has seen the first one's value -- two dependent LDS round trips on every step) */
 	const bool settled1 = ((e1 >> 7) & kFilterSlots) == slot;
@@ -1195,7 +383,7 @@ DEVINL bool frag_setup(const CompressArgs &A, Frag &F, bool gtab)
 	return true;
 }
 
-/* The dense placement's prologue (see parse_fragment_body): numbers the hash slots that two or
+/* The dense placement's prologue (see the header comment above): numbers the hash slots that two or
  * more positions of the fragment hit and writes every position's dense bucket id to the fragment's
  * workspace region.  Returns the bucket count, or kNoRecords when the fragment was handed to a
  * later launch (too many buckets, or repetitive: the global-table launch is faster for it). */
@@ -1372,15 +560,21 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	};
 	if (PROF)
 		pt_begin = pt_last = __builtin_amdgcn_s_memtime();
-	constexpr bool DENSE = TAB == TAB_LDS_DENSE;
-	static_assert(TAB != TAB_GLOBAL, "the global-table placement keeps the round-2 loop");
+	constexpr bool DENSE = TAB == TAB_LDS_DENSE, GTAB = TAB == TAB_GLOBAL;
 	static_assert(!SPILL || DENSE, "the spill-over belongs to the dense table");
+	using FT = FilterTag<DENSE ? 13 : 15>; /* dense ids are < 8192; a hash can have 15 bits */
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t n = F.n, shift = F.shift;
 	const uint8_t *src = F.src;
 	uint2 *R = F.R;
 	uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+	/* TAB_GLOBAL: the full 2^p-byte table lies in the fragment's workspace region; LDS holds one bit per
+	 * slot, "written in this fragment".  A clear bit means the slot is empty (the reference's zeroed
+	 * table: candidate position 0) without touching memory, so the global table is never cleared and
+	 * never read for empty slots. */
+	uint16_t *gtab = reinterpret_cast<uint16_t *>(F.region);
+	uint32_t *occ = reinterpret_cast<uint32_t *>(smem);
 	const uint16_t *ids = reinterpret_cast<const uint16_t *>(F.region);
 	uint16_t *spill = reinterpret_cast<uint16_t *>(F.region + A.spill_off);
 	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
@@ -1396,7 +590,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 
 	if (n >= kMargin) {
 		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
-		const uint32_t zb = DENSE ? 2 * dense_cap : 1u << F.ws;
+		const uint32_t zb = GTAB ? (1u << F.ws) >> 4 : DENSE ? 2 * dense_cap : 1u << F.ws;
 		uint4 *z4 = reinterpret_cast<uint4 *>(smem);
 		for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
 			z4[k] = make_uint4(0, 0, 0, 0);
@@ -1441,7 +635,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		/* the cursor: scan start s, and q1 = 1 + index of the next scan probe; q1 == 0: the
 		 * re-match probe at s - 1 (a copy just ended there) comes first */
 		uint32_t s = 1, q1 = 1;
-		uint32_t epoch = kFilterEpochs;
+		uint32_t epoch = FT::kEpochs;
 		bool fin = false;
 		uint32_t first4;
 		__builtin_memcpy(&first4, src, 4);
@@ -1496,12 +690,16 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			const uint32_t key2 = DENSE ? ((slot >> s_shift) ^ (slot << (s_shift - 5))) & smask
 						    : (slot >> s_shift) & smask;
 			/* slot sharing inside a step: two small filters; see filter_tag() */
-			atomicMin(&S[key], filter_tag(epoch, slot, lane, tabbed));
+			atomicMin(&S[key], FT::tag(epoch, slot, lane, tabbed));
 			if (two_filters)
-				atomicMin(&S2[key2], filter_tag(epoch, kFilterSlots - slot, lane, tabbed));
+				atomicMin(&S2[key2], FT::tag(epoch, FT::kSlots - slot, lane, tabbed));
 			uint32_t cand;
 			const bool spilled = SPILL && tabbed && slot >= dense_cap;
-			{
+			if (GTAB) {
+				const bool written = tabbed && ((occ[slot >> 5] >> (slot & 31)) & 1u);
+				cand = gtab[written ? slot : 0u];
+				cand = written ? cand : 0u;
+			} else {
 				const bool in_lds = tabbed && !spilled;
 				cand = tab[in_lds ? slot : 0u];
 				cand = in_lds ? cand : 0u;
@@ -1521,7 +719,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
 			}
 			const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
-			const bool flagged = tabbed & filter_flags(fe1, fe2, slot, lane);
+			const bool flagged = tabbed & FT::flags(fe1, fe2, slot, lane);
 			const uint64_t cmask = ballot64(flagged);
 			const uint64_t tmask = ballot64(tabbed);
 			if (--epoch == 0) {
@@ -1531,7 +729,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * A.s_entries) >> 2); k += 64)
 					s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 				wave_lds_fence();
-				epoch = kFilterEpochs;
+				epoch = FT::kEpochs;
 			}
 			uint32_t touch_a = 0, touch_b = 0;
 			tick(2); /* filters + table */
@@ -1779,8 +977,14 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						commit = false;
 				}
 			}
-			if (commit && !spilled)
+			if (GTAB) {
+				if (commit) {
+					gtab[slot] = (uint16_t)(pos_c | (chk << 15));
+					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
+				}
+			} else if (commit && !spilled) {
 				tab[slot] = (uint16_t)(pos_c | (chk << 15));
+			}
 			if (SPILL && commit && spilled)
 				spill[slot - dense_cap] = (uint16_t)(pos_c | (chk << 15));
 			wave_lds_fence();
@@ -1838,6 +1042,16 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_hash_
 	parse_lean<TAB_LDS_HASH, false>(A, F);
 }
 
+/* full table in global memory: fragments with more buckets than the dense table and its spill-over
+ * hold, and those the prologue's sample sent here (repetitive data: few steps, no prologue) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, true))
+		return;
+	parse_lean<TAB_GLOBAL, false>(A, F);
+}
+
 /* debug: the dense kernel with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
 extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_lean_prof(CompressArgs A)
 {
@@ -1854,27 +1068,6 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense
 		parse_lean<TAB_LDS_DENSE, true, true>(A, F);
 	else
 		parse_lean<TAB_LDS_DENSE, false, true>(A, F);
-}
-
-/* debug instantiations with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_prof(CompressArgs A)
-{
-	parse_fragment_body<true, TAB_LDS_HASH>(A);
-}
-
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_prof(CompressArgs A)
-{
-	parse_fragment_body<true, TAB_LDS_DENSE>(A);
-}
-
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_prof(CompressArgs A)
-{
-	parse_fragment_body<true, TAB_GLOBAL>(A);
-}
-
-extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_spill_prof(CompressArgs A)
-{
-	parse_fragment_body<true, TAB_LDS_DENSE, true>(A);
 }
 
 /* ==========================================================================================
@@ -2280,9 +1473,11 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
  *      other with the whole wave, dst[j] = dst[j mod offset - offset]  (:188-206 semantics).
  * ======================================================================================== */
 
-/* copy exactly len (<= 64) bytes, global -> global, non-overlapping, any alignment: the pieces
- * 16,16,16,16 / 8 / 4 / 2 / 1 that make up len are all loaded first (one memory round trip for
- * the lane, whatever its length), then all stored */
+/* copy exactly len (<= 64) bytes from global memory into the wave's LDS staging, any alignment:
+ * the pieces 16,16,16,16 / 8 / 4 / 2 / 1 that make up len are all loaded first (one memory round
+ * trip for the lane, whatever its length), then all stored.  (Unconditional stores, with the pieces
+ * a lane does not have sent to a scrap slot -- selects instead of exec-mask regions -- change
+ * nothing: measured in round 3.) */
 DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, uint64_t &carried)
 {
 	const uint32_t n16 = active ? len >> 4 : 0; /* 0..4 */
@@ -2341,6 +1536,7 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, 
 		d[o1] = p1;
 }
 
+constexpr int kWalkGroup = 4; /* tags per end-of-walk test in the decompress scan */
 constexpr uint32_t kOutStage = 2048; /* bytes of a batch's output assembled in LDS */
 
 /* The reference's char_table (csnappy_decompress.c:152-185) as the kernels use it, computed by
@@ -2458,16 +1654,17 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			/* The walk: two instructions per tag (s_bitset1 + v_readlane) in groups of four.  A step
 			 * that leaves the window goes back to lane 0, where the walk only marks tags again that
 			 * are marked already, so the end is tested once per group: the steps taken no longer
-			 * equal the tags marked.  (The scalar unit is the busiest one in this kernel.) */
+			 * equal the tags marked.  (Marking with v_writelane instead -- no scalar instruction per
+			 * tag at all -- was measured in round 3: 2.31 against 2.28 ms, groups of 4 or 8.) */
 			const uint32_t nxw = nxt < wlim ? nxt : 0u;
 			uint32_t steps = 0;
 			do {
 #pragma unroll
-				for (int kk = 0; kk < 4; ++kk) {
+				for (int kk = 0; kk < kWalkGroup; ++kk) {
 					asm("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(cur));
 					cur = rdlane(nxw, cur);
 				}
-				steps += 4;
+				steps += kWalkGroup;
 			} while ((uint32_t)__builtin_popcountll(tmask) == steps);
 			cur = rdlane(nxt, 63u - (uint32_t)__builtin_clzll(tmask)); /* where the last tag's element ends */
 			/* request the next iteration's bytes now */
@@ -3412,7 +2609,6 @@ struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
 	bool ok;
-	bool old_parser; /* CSNAPPY_HIP_PARSER=old: the round-2 step loop (A/B timing) */
 };
 
 bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
@@ -3430,9 +2626,7 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true, false };
-	if (const char *e = getenv("CSNAPPY_HIP_PARSER"))
-		k.old_parser = !strcmp(e, "old");
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true };
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -3744,32 +2938,13 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.p = p;
 	A.mode = mode;
 
-	const void *kfns[3][2] = {
-		{ reinterpret_cast<const void *>(snappy_parse_fragments),
-		  reinterpret_cast<const void *>(snappy_parse_fragments_prof) },
-		{ reinterpret_cast<const void *>(snappy_parse_fragments_dense),
-		  reinterpret_cast<const void *>(snappy_parse_fragments_dense_prof) },
-		{ reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
-		  reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof) },
-	};
-	const void *k1 = (P.tab == TAB_LDS_DENSE && !P.spill_cap && !g_prof_buf)
-				 ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_whole)
-				 : kfns[P.tab][g_prof_buf ? 1 : 0];
-	const bool lean_prof = g_prof_buf && !kn.old_parser && P.tab == TAB_LDS_DENSE;
-	if (!g_prof_buf && !kn.old_parser) {
-		if (P.tab == TAB_LDS_DENSE)
-			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean);
-		else if (P.tab == TAB_LDS_HASH && (1u << (p - 1)) <= kFilterSlots + 1) /* (its filter tags hold 13-bit slots) */
-			k1 = reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean);
-	}
-	if (lean_prof)
-		k1 = reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof);
-	const void *k2 = kfns[TAB_GLOBAL][g_prof_buf ? 1 : 0];
-	const void *ks = reinterpret_cast<const void *>(snappy_parse_fragments_dense_spill_prof);
-	if (P.spill_cap && g_prof_buf &&
-	    !hip_ok(hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
-		    "hipFuncSetAttribute"))
-		return CSNAPPY_HIP_E_RUNTIME;
+	/* (the s_memtime phase counters of tools/phase_lean.py exist for the dense placement only) */
+	const void *k1 = P.tab == TAB_LDS_DENSE
+				 ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof)
+					       : reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean))
+			 : P.tab == TAB_LDS_HASH ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean)
+						 : reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
+	const void *k2 = reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
 	if (!hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
 		    "hipFuncSetAttribute") ||
 	    (P.fallback &&
@@ -3794,16 +2969,6 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
 			    "launch snappy_parse_fragments"))
 			return CSNAPPY_HIP_E_RUNTIME;
-		if (P.spill_cap && g_prof_buf && !lean_prof) {
-			/* (the profiling build of the dense kernel has no spill-over inside: what overflowed
-			 * its LDS table by a little runs here, same geometry, the overflow in HBM) */
-			A.sample_min = 0;
-			A.only_unparsed = 1;
-			if (!hip_ok(hipLaunchKernel(ks, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
-				    "launch snappy_parse_fragments_dense_spill"))
-				return CSNAPPY_HIP_E_RUNTIME;
-			A.sample_min = P.sample_min;
-		}
 		if (P.cap2) {
 			A.lds0 = P.lds0_2;
 			A.s_entries = P.s_entries_2;
