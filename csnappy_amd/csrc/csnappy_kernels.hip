@@ -1536,7 +1536,25 @@ DEVINL void copy_exact(uint8_t *d, const uint8_t *s, uint32_t len, bool active, 
 		d[o1] = p1;
 }
 
-constexpr int kWalkGroup = 4; /* tags per end-of-walk test in the decompress scan */
+#ifndef CSNAPPY_DEC_WALK4
+#define CSNAPPY_DEC_WALK4 1
+#endif
+#ifndef CSNAPPY_DEC_PROF
+#define CSNAPPY_DEC_PROF 0
+#endif
+#if CSNAPPY_DEC_PROF
+/* development builds only (tools/build_variant.sh <name> -DCSNAPPY_DEC_PROF=1, tools/phase_dec.py):
+ * s_memtime phase counters of the decompress kernel */
+__device__ unsigned long long g_dec_prof[32];
+#define DEC_TICK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - pt_last; pt_last = now_; } while (0)
+#define DEC_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DEC_COUNT(k, v) (pc[k] += (v))
+#else
+#define DEC_TICK(k) do { } while (0)
+#define DEC_WAIT_VM() do { } while (0)
+#define DEC_COUNT(k, v) do { } while (0)
+#endif
+constexpr int kWalkGroup = 4; /* tags per end-of-walk test where the plain walk is used */
 constexpr uint32_t kOutStage = 2048; /* bytes of a batch's output assembled in LDS */
 
 /* The reference's char_table (csnappy_decompress.c:152-185) as the kernels use it, computed by
@@ -1596,6 +1614,11 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		limit = olen;
 	}
 
+#if CSNAPPY_DEC_PROF
+	unsigned long long pt[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, pc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
+	unsigned long long pt_last = pt_begin;
+#endif
 	uint32_t op = 0;        /* bytes produced */
 	uint64_t next8 = 0;     /* the 8 input bytes at the next scan iteration's ip + lane */
 	bool have_next = false; /* ... valid for every lane */
@@ -1615,6 +1638,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		 * only the real tags in phase 2 was tried: fewer instructions, but one more dependent
 		 * global round trip per batch -- 2.41 -> 2.85 ms per GiB of text.) */
 		while (qn < 64 && ip < n) {
+			DEC_TICK(11); /* (whatever ran since the last tick) */
+			DEC_COUNT(1, 1);
+			DEC_WAIT_VM();
+			DEC_TICK(0); /* scan: wait for the window's bytes */
 			const uint32_t at = ip + lane;
 			uint32_t b0 = 0, tr = 0;
 			if (have_next) {
@@ -1657,7 +1684,47 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			 * equal the tags marked.  (Marking with v_writelane instead -- no scalar instruction per
 			 * tag at all -- was measured in round 3: 2.31 against 2.28 ms, groups of 4 or 8.) */
 			const uint32_t nxw = nxt < wlim ? nxt : 0u;
+#if CSNAPPY_DEC_PROF
+			asm volatile("" : : "v"(nxw), "v"(nxt));
+#endif
+			DEC_TICK(1); /* scan: decode */
 			uint32_t steps = 0;
+#if CSNAPPY_DEC_WALK4
+			{
+				/* Four tags per dependent step.  What a hop costs is not its instructions but the
+				 * trip of v_readlane's result to the scalar register file (some 40 cycles before the
+				 * next instruction that uses it may issue): the tables of the 2nd, 3rd and 4th
+				 * successors (three ds_bpermute per window) let the wave fetch four tags' worth of
+				 * lanes back to back and pay that trip once.  A walk that left the window goes on
+				 * around the same chain (lane 0 follows the last tag), so the tags are marked in
+				 * chain order, none is skipped, and the first tag marked twice ends it as before. */
+				const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxw << 2), (int)nxw);
+				const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(n2 << 2), (int)nxw);
+				const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(n2 << 2), (int)n2);
+				do {
+					uint32_t ta, tb, tc, tf;
+					asm volatile("v_readlane_b32 %5, %9, %1\n\t"
+						     "v_readlane_b32 %2, %6, %1\n\t"
+						     "v_readlane_b32 %3, %7, %1\n\t"
+						     "v_readlane_b32 %4, %8, %1\n\t"
+						     "s_bitset1_b64 %0, %1\n\t"
+						     "s_bitset1_b64 %0, %2\n\t"
+						     "s_bitset1_b64 %0, %3\n\t"
+						     "s_bitset1_b64 %0, %4\n\t"
+						     "v_readlane_b32 %1, %9, %5\n\t"
+						     "v_readlane_b32 %2, %6, %5\n\t"
+						     "v_readlane_b32 %3, %7, %5\n\t"
+						     "v_readlane_b32 %4, %8, %5\n\t"
+						     "s_bitset1_b64 %0, %5\n\t"
+						     "s_bitset1_b64 %0, %2\n\t"
+						     "s_bitset1_b64 %0, %3\n\t"
+						     "s_bitset1_b64 %0, %4"
+						     : "+s"(tmask), "+s"(cur), "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(tf)
+						     : "v"(nxw), "v"(n2), "v"(n3), "v"(n4));
+					steps += 8;
+				} while ((uint32_t)__builtin_popcountll(tmask) == steps);
+			}
+#else
 			do {
 #pragma unroll
 				for (int kk = 0; kk < kWalkGroup; ++kk) {
@@ -1666,7 +1733,9 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				}
 				steps += kWalkGroup;
 			} while ((uint32_t)__builtin_popcountll(tmask) == steps);
+#endif
 			cur = rdlane(nxt, 63u - (uint32_t)__builtin_clzll(tmask)); /* where the last tag's element ends */
+			DEC_TICK(2); /* scan: walk */
 			/* request the next iteration's bytes now */
 			have_next = cur < room && room - cur >= 64 + 8;
 			if (have_next)
@@ -1677,10 +1746,13 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			}
 			qn += (uint32_t)__builtin_popcountll(tmask);
 			ip = cur >= room ? n : ip + cur;
+			DEC_TICK(3); /* scan: next request, queue write */
 		}
 		if (qn == 0)
 			break;
+		DEC_COUNT(0, 1);
 		wave_lds_fence();
+		DEC_TICK(11);
 		/* ================= phase 2: execute up to 64 elements, one lane each ===================== */
 		const uint32_t m = min(qn, 64u);
 		const bool live = lane < m;
@@ -1720,6 +1792,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		const uint32_t nrun = fe < 64 ? fe : m;
 		const uint64_t fitmask = ballot64(exec_me && excl + l <= kOutStage);
 		const uint32_t nfit = ~fitmask ? first_lane(~fitmask) : 64u;
+		DEC_TICK(4); /* queue read, checks, offsets */
+		DEC_COUNT(2, nfit);
 		if (nfit == 0 && nrun > 0) {
 			/* the first element does not fit: a long literal (copies are <= 64 bytes).  4 x 16 B per
 			 * lane per iteration straight to HBM (the four loads are issued before the first store
@@ -1752,6 +1826,8 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			op += L;
 			qh = (qh + 1) & 127u;
 			qn -= 1;
+			DEC_TICK(10); /* long literal, straight to HBM */
+			DEC_COUNT(5, 1);
 			continue;
 		}
 		if (nfit > 0) {
@@ -1764,6 +1840,9 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			/* ---- literals up to 64 bytes (SAW__Append / SAW__AppendFastPath, :264-293) and copies
 			 * that read only what earlier batches produced, one lane per element ---- */
 			copy_exact(o, lit ? src + (at + hsz) : dst + pb - off, l, (lit && l <= 64) || indep, next8);
+			DEC_TICK(6); /* one-lane copies: round trip, piece stores */
+			DEC_COUNT(3, __builtin_popcountll(ballot64(cpy && !indep)));
+			DEC_COUNT(4, __builtin_popcountll(ballot64(lit && l > 64)));
 			/* ---- longer literals: wave-wide, 16 B per lane ---- */
 			for (uint64_t big = ballot64(lit && l > 64); big;) {
 				const uint32_t t = first_lane(big);
@@ -1781,6 +1860,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 					pd[body + lane] = ps[body + lane];
 			}
 			wave_lds_fence();
+			DEC_TICK(7); /* literals of more than 64 bytes */
 			/* ---- the other copies, in order (SAW__AppendFromSelf, :295-317): source inside this
 			 * batch's output or overlapping itself, dst[j] = dst[j mod offset - offset]; bytes from
 			 * in front of the batch come from HBM, the rest from the staging ---- */
@@ -1789,7 +1869,15 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				asm("s_bitset0_b64 %0, %1" : "+s"(dep) : "s"(t));
 				const uint32_t L = rdlane(l, t), OFF = rdlane(off, t), E = rdlane(excl, t);
 				if (lane < L) {
-					const uint32_t j = lane < OFF ? lane : lane % OFF;
+					/* lane mod OFF for lane < 64 (a self-overlapping copy only; the generic 32-bit
+					 * remainder is two dozen instructions): the quotient by a float reciprocal can
+					 * only come out one too small, at exact multiples */
+					uint32_t j = lane;
+					if (OFF < L) {
+						const uint32_t q = (uint32_t)((float)lane * __builtin_amdgcn_rcpf((float)OFF));
+						const uint32_t r = lane - q * OFF;
+						j = min(r, r - OFF);
+					}
 					const int32_t s = (int32_t)(E + j) - (int32_t)OFF; /* relative to the batch's start */
 					uint32_t byte = ostage[sa + (uint32_t)max(s, 0)];
 					asm volatile("" : "+v"(byte)); /* keeps the two loads apart (merged, they become one flat load) */
@@ -1799,6 +1887,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				}
 				wave_lds_fence();
 			}
+			DEC_TICK(8); /* dependent copies */
 			/* ---- flush ---- */
 			{
 				const uint32_t total = rdlane(excl, nfit - 1) + rdlane(l, nfit - 1);
@@ -1821,6 +1910,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				op += total;
 				wave_lds_fence();
 			}
+			DEC_TICK(9); /* flush */
 		}
 		if (fe < 64 && nfit == nrun) {
 			status = (int32_t)rdlane((uint32_t)err, fe);
@@ -1830,6 +1920,16 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		qn -= nfit;
 	}
 
+#if CSNAPPY_DEC_PROF
+	if (lane == 0) {
+		atomicAdd(&g_dec_prof[0], __builtin_amdgcn_s_memtime() - pt_begin);
+		for (int k = 0; k < 12; ++k)
+			atomicAdd(&g_dec_prof[1 + k], pt[k]);
+		for (int k = 0; k < 8; ++k)
+			atomicAdd(&g_dec_prof[16 + k], pc[k]);
+		atomicAdd(&g_dec_prof[24], 1ull);
+	}
+#endif
 	if (lane == 0) {
 		A.status[blk] = status;
 		/* on -3 / -5 the decoded prefix is in dst, as after the reference's write-as-you-go
@@ -2848,6 +2948,17 @@ void csnappy_hip_debug_set_profile_buffer(void *d_buf)
 {
 	g_prof_buf = static_cast<unsigned long long *>(d_buf);
 }
+
+#if CSNAPPY_DEC_PROF
+/* development builds only: read (and clear) the decompress kernel's phase counters */
+int csnappy_hip_debug_dec_prof(unsigned long long *out32)
+{
+	static const unsigned long long zero[32] = { 0 };
+	if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_dec_prof), sizeof(zero)) != hipSuccess)
+		return -1;
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_dec_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 /* debug only (not in the public header): read the CSNAPPY_HIP_* environment knobs again.  For
  * tests that switch table placements inside one process; not to be called while a batch call runs. */
