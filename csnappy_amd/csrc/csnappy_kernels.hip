@@ -649,7 +649,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		auto place = [&]() {
 			pos = s + q1 - 2 + lane;
 			valid = pos < ip_limit;
-			if (q1 > 32) {
+			if (__builtin_expect(q1 > 32, 0)) {
 				/* sparse: the next 64 probes of the stride rule; a probe happens only if the
 				 * NEXT position is still <= ip_limit (:542-544) */
 				pos = scan_pos(s, q1 - 1 + lane);
@@ -711,7 +711,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			wave_lds_fence();
 			/* the candidate's 16 bytes are requested as soon as the table entry is there, in front of
 			 * the filters' read-back (dense steps; lanes without a candidate read position 0 -- one
-			 * broadcast line, cheaper than masking the load off) */
+			 * broadcast line; masking them off the load, here and in the spill-over gather, changes
+			 * nothing: measured in round 3) */
 			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
 			cand &= 0x7fffu;
 			uint4 w4 = make_uint4(0, 0, 0, 0);
@@ -844,12 +845,17 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				uint64_t taken = 0; /* lanes whose match is part of the chain */
 				tick(4); /* match lengths, next-stop table */
 				for (;;) {
-					/* plain matches: hop from match to match */
-					while (t < 64) {
-						const uint32_t i = t;
-						t = rdlane(nx, i);
-						asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */
-					}
+					/* plain matches: hop from match to match (unrolling this loop four times was
+					 * measured in round 3: no gain) */
+#define CSNAPPY_HOP()                                                                              \
+	{                                                                                          \
+		const uint32_t i = t;                                                              \
+		t = rdlane(nx, i);                                                                 \
+		asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */       \
+	}
+					while (t < 64)
+						CSNAPPY_HOP();
+#undef CSNAPPY_HOP
 					if (t < 128)
 						break;
 					const uint32_t i = t & 63u;
@@ -915,13 +921,18 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t c = rdlane(cl, last); /* (no copy: lane 0's, unused) */
 				const uint32_t ip = p0 + c;
 				const bool end_a = t == 64;
-				const uint32_t lim = any ? c + 32 : lim0;
+				/* (masks, not ?: -- the compiler turns a chain of selects on the cursor into branches,
+				 * and a taken branch costs a lone wave four instructions' time) */
+				const uint32_t m_any = 0u - (uint32_t)any, m_a = 0u - (uint32_t)end_a;
+				const uint32_t lim = (m_any & (c + 32)) | (~m_any & lim0);
 				const uint32_t e = min(lim, ulim - 1);
-				e_final = end_a ? last : e;
-				fin = end_a ? ip >= ip_limit /* :585-586 */ : (ulim <= lim && ulim < 64);
-				next_emit = any ? ip : next_emit;
-				q1 = end_a ? 0u : any ? e + 1 - c : q1 + e;
-				s = any ? ip + 1 : s;
+				e_final = (m_a & last) | (~m_a & e);
+				const uint32_t fin_a = ip >= ip_limit; /* :585-586 */
+				const uint32_t fin_b = (uint32_t)(ulim <= lim) & (uint32_t)(ulim < 64);
+				fin = ((m_a & fin_a) | (~m_a & fin_b)) != 0;
+				next_emit = (m_any & ip) | (~m_any & next_emit);
+				q1 = ~m_a & ((m_any & (e + 1 - c)) | (~m_any & (q1 + e)));
+				s = (m_any & (ip + 1)) | (~m_any & s);
 				/* the cursor of the next step is known: fetch its bytes now (after the last step the
 				 * loads are harmless: an invalid lane reads position 0) */
 				place();

@@ -14,7 +14,7 @@ kind, seed, block, p, mode = {"text": (0, 0xC5A90001, 65536, 16, 0), "low": (1, 
                               "page": (2, 0xC5A90004, 4096, 13, 1), "urls": (-1, 0, 65536, 16, 0)}[sys.argv[1] if len(sys.argv) > 1 else "text"]
 if len(sys.argv) > 2:
     p = int(sys.argv[2])
-nb = (256 << 20) // block
+nb = (int(os.environ.get('PHASE_MIB', '256')) << 20) // block
 if kind >= 0:
     d_in = api.generate(kind, seed, 0, nb, block)
 else:
