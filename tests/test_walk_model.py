@@ -56,14 +56,15 @@ def test_four_tag_walk_marks_exactly_the_chain():
 
 
 def test_float_reciprocal_remainder_is_exact_within_one_ulp_of_the_reciprocal():
-    """The self-overlapping copy's `lane mod OFF` (lane < 64, OFF < 64): quotient by a float
-    reciprocal, one correction.  v_rcp_f32 is accurate to 1 ulp: every reciprocal within one ulp
-    of the rounded one must still give the exact remainder."""
-    lane = np.arange(64, dtype=np.uint32)
-    for off in range(1, 64):
+    """The self-overlapping copy's `lane mod OFF` (the kernel needs lane < 64, OFF < 64; checked
+    here far beyond that): quotient by a float reciprocal, one correction.  v_rcp_f32 is accurate
+    to 1 ulp: every reciprocal within one ulp of the rounded one must still give the exact
+    remainder."""
+    j = np.arange(64 * 65, dtype=np.uint32)
+    for off in range(1, 64 * 65):
         r0 = np.float32(1.0) / np.float32(off)
         for rcp in (np.nextafter(r0, np.float32(0)), r0, np.nextafter(r0, np.float32(2))):
-            q = (lane.astype(np.float32) * np.float32(rcp)).astype(np.uint32)  # v_cvt_u32_f32 truncates
-            r = (lane - q * np.uint32(off)).astype(np.uint32)
-            j = np.minimum(r, (r - np.uint32(off)).astype(np.uint32))
-            assert np.array_equal(j, lane % off), (off, float(rcp))
+            q = (j.astype(np.float32) * np.float32(rcp)).astype(np.uint32)  # v_cvt_u32_f32 truncates
+            r = (j - q * np.uint32(off)).astype(np.uint32)
+            got = np.minimum(r, (r - np.uint32(off)).astype(np.uint32))
+            assert np.array_equal(got, j % off), (off, float(rcp))
