@@ -1144,9 +1144,28 @@ DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t
 /* `ahead` = the loads already issued for the wave's next chunk: they are waited for in front of
  * this chunk's stores (gfx9 has one counter for loads and stores; a wait behind the stores would
  * also sit out their round trip) */
+#ifndef CSNAPPY_EMIT_NOBIG
+#define CSNAPPY_EMIT_NOBIG 0
+#endif
+#ifndef CSNAPPY_EMIT_PROF
+#define CSNAPPY_EMIT_PROF 0
+#endif
+#if CSNAPPY_EMIT_PROF
+/* development builds only (tools/build_variant.sh <name> -DCSNAPPY_EMIT_PROF=1, tools/phase_emit.py) */
+__device__ unsigned long long g_emit_prof[16];
+#define EMIT_TICK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ept[k] += now_ - ept_last; ept_last = now_; } while (0)
+#define EMIT_PROF_ARG , unsigned long long *ept
+#else
+#define EMIT_TICK(k) do { } while (0)
+#define EMIT_PROF_ARG
+#endif
 DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, const uint8_t *src, uint32_t avail,
-			   uint8_t *dst, uint8_t *stage, uint32_t lane)
+			   uint8_t *dst, uint8_t *stage, uint32_t lane EMIT_PROF_ARG)
 {
+#if CSNAPPY_EMIT_PROF
+	unsigned long long ept_last = __builtin_amdgcn_s_memtime();
+	ept[7] += 1;
+#endif
 	/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
 	 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
 	uint32_t gpos = 0, fill = 0;
@@ -1189,6 +1208,10 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	const uint32_t excl = wave_excl_scan(mine, lane, &total);
 	const uint32_t lw[8] = { in.la.x, in.la.y, in.la.z, in.la.w, in.lb.x, in.lb.y, in.lb.z, in.lb.w };
 	uint32_t seg_lo = 0; /* first record of the current run of small records */
+#if CSNAPPY_EMIT_PROF
+	asm volatile("" : : "v"(excl), "v"(lw[0]), "v"(lw[7]));
+#endif
+	EMIT_TICK(0); /* decode, offsets (and the wait for the chunk's own loads) */
 	while (nev) {
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
 		if (seg_hi > seg_lo) {
@@ -1208,6 +1231,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 					__builtin_memcpy(o + lhdr + 4 * k, &lw[k], 4);
 			}
 			wave_lds_fence();
+			EMIT_TICK(1); /* literal payload into the staging */
 			if (in_run) {
 				if (lhdr == 1) {
 					o[0] = (uint8_t)((lit_len - 1) << 2);
@@ -1241,18 +1265,40 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 				}
 			}
 			fill += run_bytes;
+			EMIT_TICK(2); /* literal headers, copy tags */
 		}
+#if CSNAPPY_EMIT_NOBIG
+		break; /* (timing experiment only: wrong output) */
+#endif
 		if (!bigmask)
 			break;
-		/* ---- a big record: drain the staging, write it straight to HBM ---- */
+		/* ---- a big record: drain the staging, write it straight to HBM ----
+		 * Its literal's first 256 + 6 bytes are requested BEFORE the drain and waited for in front
+		 * of the drain's stores: gfx9 counts loads and stores in one counter, and a load issued
+		 * behind a store is not back before the store is acknowledged -- four such waits per big
+		 * record (head, words, tail behind the drain's and each other's stores) were more than
+		 * half of this kernel's time on text, at 0.4 big records per 64. */
 		const uint32_t e = first_lane(bigmask);
 		bigmask &= bigmask - 1;
-		drain();
 		const uint32_t ls = rdlane(lit_start, e), ll = rdlane(lit_len, e);
 		const uint32_t lh = rdlane(lhdr, e), co = rdlane(coff, e), cl = rdlane(clen, e);
 		const uint32_t k64 = rdlane(cp.k64, e), k60 = rdlane(cp.k60, e), last = rdlane(cp.last, e);
 		const uint32_t cbytes = rdlane(cp.bytes, e);
-		uint8_t *o = dst + gpos;
+		uint8_t *o = dst + gpos + fill; /* (where the drain will leave the cursor) */
+		uint8_t *d = o + lh;
+		/* literal payload: destination-aligned dwords from the input */
+		const uint32_t head = min(ll, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
+		const uint32_t words = (ll - head) >> 2;
+		const uint32_t t0 = head + 4 * words;
+		uint32_t hb = 0, w0 = 0, tb = 0;
+		if (lane < head)
+			hb = src[ls + lane];
+		if (lane < words)
+			__builtin_memcpy(&w0, src + ls + head + 4 * lane, 4);
+		if (t0 + lane < ll)
+			tb = src[ls + t0 + lane];
+		asm volatile("" : "+v"(hb), "+v"(w0), "+v"(tb));
+		drain();
 		if (lane == 0) {
 			const uint32_t v = ll - 1;
 			if (lh == 1) {
@@ -1267,21 +1313,29 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 			}
 		}
 		{
-			/* literal payload: destination-aligned dwords from the input */
-			uint8_t *d = o + lh;
-			const uint32_t head = min(ll, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3));
-			if (lane < head)
-				d[lane] = src[ls + lane];
-			const uint32_t words = (ll - head) >> 2;
 			uint32_t *d32 = reinterpret_cast<uint32_t *>(d + head);
-			for (uint32_t k = lane; k < words; k += 64) {
-				uint32_t w;
-				__builtin_memcpy(&w, src + ls + head + 4 * k, 4);
-				d32[k] = w;
-			}
-			const uint32_t t0 = head + 4 * words;
+			if (lane < head)
+				d[lane] = (uint8_t)hb;
+			if (lane < words)
+				d32[lane] = w0;
 			if (t0 + lane < ll)
-				d[t0 + lane] = src[ls + t0 + lane];
+				d[t0 + lane] = (uint8_t)tb;
+			/* longer literals: 1 KiB per round trip */
+			for (uint32_t k = 64 + lane; k < words; k += 256) {
+				const uint32_t lastw = words - 1;
+				uint32_t v0, v1, v2, v3;
+				__builtin_memcpy(&v0, src + ls + head + 4 * min(k, lastw), 4);
+				__builtin_memcpy(&v1, src + ls + head + 4 * min(k + 64u, lastw), 4);
+				__builtin_memcpy(&v2, src + ls + head + 4 * min(k + 128u, lastw), 4);
+				__builtin_memcpy(&v3, src + ls + head + 4 * min(k + 192u, lastw), 4);
+				d32[k] = v0;
+				if (k + 64u < words)
+					d32[k + 64u] = v1;
+				if (k + 128u < words)
+					d32[k + 128u] = v2;
+				if (k + 192u < words)
+					d32[k + 192u] = v3;
+			}
 		}
 		if (cl) {
 			uint8_t *q = o + lh + ll;
@@ -1304,13 +1358,16 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 		gpos += lh + ll + cbytes;
 		sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
 		seg_lo = e + 1;
+		EMIT_TICK(3); /* a big record */
 	}
 	drain();
+	EMIT_TICK(4); /* drain */
 	return gpos;
 }
 
 constexpr uint32_t kEmitWaves = 4;
-constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records) */
+constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records): their totals fit the first 1 KiB of its id region */
+static_assert(kMaxChunks * 4 <= 1024, "chunk totals live in the smallest id region");
 
 /* small blocks (pages): one wave per block, chunks in order, no size pass.  (A kernel of its own:
  * inlined beside the workgroup-per-block path below, the two copies of emit_chunk cost the
@@ -1359,24 +1416,93 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pag
 			r2 = fetch_record(R, r0 + 128, min(64u, cnt - r0 - 128), lane);
 		if (r0 + 64 < cnt)
 			fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
+#if CSNAPPY_EMIT_PROF
+		unsigned long long ept_pages[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane, ept_pages);
+#else
 		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane);
+#endif
 	}
 	if (lane == 0)
 		A.out_len[blk] = pos;
 	return;
 }
 
-extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blocks(CompressArgs A)
+/* Blocks of more than 8 KiB: three launches over the chunk of the batch, no barrier anywhere.
+ *   snappy_emit_sizes   one workgroup per FRAGMENT: the encoded bytes of each of its 64-record
+ *                       chunks (the parser's id / table region of the fragment is free by now and
+ *                       takes the <= 129 totals)
+ *   snappy_emit_bases   one wave per BLOCK: the length prefix, then the totals of its fragments'
+ *                       chunks, in order, turned into their offsets in the block's slot
+ *                       (fragment k+1 starts where fragment k ended, :647-653); out_len
+ *   snappy_emit_blocks  one workgroup per FRAGMENT: every wave encodes its 64-record chunks at
+ *                       their final place
+ * (Until round 3 one workgroup did all of this for a whole block, fragment after fragment, with
+ * three barriers per fragment: a block's waves waited for each other, and a long single stream
+ * was emitted by one workgroup.) */
+struct EmitFrag {
+	uint32_t blk, fi, len, cnt, nchunks;
+	const uint2 *R;
+	uint32_t *base; /* per 64-record chunk: encoded bytes (after snappy_emit_sizes), then offset in the block's slot */
+};
+
+/* false: the fragment does not exist, or its block cannot be emitted (snappy_emit_bases reports it) */
+DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
-	__shared__ uint32_t chunk_tot[kMaxChunks];
-	__shared__ uint32_t chunk_base[kMaxChunks + 1];
+	const uint32_t c = blockIdx.x;
+	F.blk = A.blk_base + c / A.fpb;
+	F.fi = c % A.fpb;
+	F.len = A.in_len[F.blk];
+	if (F.len > A.max_in_len)
+		return false;
+	const uint32_t nfr = F.len ? (F.len + kFragment - 1) / kFragment : 1;
+	if (F.fi >= nfr)
+		return false;
+	F.cnt = A.rec_cnt[c];
+	if (F.cnt >= kWantGlobal)
+		return false;
+	F.nchunks = (F.cnt + 63) >> 6;
+	F.R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
+	F.base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)c * A.tab_stride);
+	return true;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_sizes(CompressArgs A)
+{
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	EmitFrag F;
+	if (!emit_frag_setup(A, F))
+		return;
+	/* encoded bytes of every 64-record chunk (four chunks' records in flight) */
+	for (uint32_t c0 = wv; c0 < F.nchunks; c0 += 4 * kEmitWaves) {
+		uint2 rr[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			const uint32_t r = (c0 + j * kEmitWaves) * 64 + lane;
+			rr[j] = r < F.cnt ? F.R[r] : make_uint2(0, 0);
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			const uint32_t ch = c0 + j * kEmitWaves;
+			if (ch < F.nchunks) {
+				const RecFields f = decode_record(rr[j], ch * 64 + lane < F.cnt);
+				uint32_t total;
+				(void)wave_excl_scan(f.mine, lane, &total);
+				if (lane == 0)
+					F.base[ch] = total;
+			}
+		}
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(64) snappy_emit_bases(CompressArgs A)
+{
+	const uint32_t lane = threadIdx.x;
 	const uint32_t blk = A.blk_base + blockIdx.x;
 	const uint32_t len = A.in_len[blk];
 	if (len > A.max_in_len) {
 		/* the precondition in_len[b] <= max_in_len is violated: nothing was parsed for this block */
-		if (tid == 0)
+		if (lane == 0)
 			A.out_len[blk] = 0xffffffffu;
 		return;
 	}
@@ -1385,7 +1511,7 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 	 * instead of spinning when their cursor stops moving): the block is reported as failed */
 	for (uint32_t fi = 0; fi < nfr; ++fi) {
 		if (A.rec_cnt[blockIdx.x * A.fpb + fi] >= kWantGlobal) {
-			if (tid == 0)
+			if (lane == 0)
 				A.out_len[blk] = 0xffffffffu;
 			return;
 		}
@@ -1395,80 +1521,77 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 	if (A.mode == CSNAPPY_HIP_STREAM) {
 		/* encode_varint32, csnappy_compress.c:46-73 */
 		pos = varint_len(len);
-		if (tid < pos)
-			dst[tid] = (uint8_t)((len >> (7 * tid)) | (tid + 1 < pos ? 0x80u : 0u));
+		if (lane < pos)
+			dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
 	}
 	for (uint32_t fi = 0; fi < nfr; ++fi) {
 		const uint32_t c = blockIdx.x * A.fpb + fi;
-		const uint32_t cnt = A.rec_cnt[c];
-		const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
-		const uint8_t *src = A.in + A.in_off[blk] + fi * kFragment;
-		const uint32_t avail = len - fi * kFragment;
-		const uint32_t nchunks = (cnt + 63) >> 6;
-		/* pass 1: encoded bytes of every 64-record chunk (four chunks' records in flight) */
-		for (uint32_t c0 = wv; c0 < nchunks; c0 += 4 * kEmitWaves) {
-			uint2 rr[4];
-#pragma unroll
-			for (uint32_t j = 0; j < 4; ++j) {
-				const uint32_t r = (c0 + j * kEmitWaves) * 64 + lane;
-				rr[j] = r < cnt ? R[r] : make_uint2(0, 0);
-			}
-#pragma unroll
-			for (uint32_t j = 0; j < 4; ++j) {
-				const uint32_t ch = c0 + j * kEmitWaves;
-				if (ch < nchunks) {
-					const RecFields f = decode_record(rr[j], ch * 64 + lane < cnt);
-					uint32_t total;
-					(void)wave_excl_scan(f.mine, lane, &total);
-					if (lane == 0)
-						chunk_tot[ch] = total;
-				}
-			}
+		const uint32_t nchunks = (A.rec_cnt[c] + 63) >> 6;
+		uint32_t *base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)c * A.tab_stride);
+		/* exclusive scan of the chunk totals (<= 129 entries) */
+		for (uint32_t b0 = 0; b0 < nchunks; b0 += 64) {
+			const uint32_t ch = b0 + lane;
+			const uint32_t v = ch < nchunks ? base[ch] : 0;
+			uint32_t total;
+			const uint32_t ex = wave_excl_scan(v, lane, &total);
+			if (ch < nchunks)
+				base[ch] = pos + ex;
+			pos += total;
 		}
-		__syncthreads();
-		if (wv == 0) {
-			/* exclusive scan of the chunk totals (<= 129 entries) */
-			uint32_t run = pos;
-			for (uint32_t b0 = 0; b0 < nchunks; b0 += 64) {
-				const uint32_t ch = b0 + lane;
-				const uint32_t v = ch < nchunks ? chunk_tot[ch] : 0;
-				uint32_t total;
-				const uint32_t ex = wave_excl_scan(v, lane, &total);
-				if (ch < nchunks)
-					chunk_base[ch] = run + ex;
-				run += total;
-			}
-			if (lane == 0)
-				chunk_base[nchunks] = run;
-		}
-		__syncthreads();
-		/* pass 2: every wave encodes its chunks at their final place (records fetched two of
-		 * its chunks ahead, literal bytes one ahead) */
-		{
-			ChunkIn cur, nxt;
-			auto cn = [&](uint32_t ch) { return min(64u, cnt - ch * 64); };
-			uint2 r2 = make_uint2(0, 0);
-			if (wv < nchunks) {
-				nxt.r = fetch_record(R, wv * 64, cn(wv), lane);
-				if (wv + kEmitWaves < nchunks)
-					r2 = fetch_record(R, (wv + kEmitWaves) * 64, cn(wv + kEmitWaves), lane);
-				fetch_literal(nxt, cn(wv), src, avail, lane);
-			}
-			for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
-				cur = nxt;
-				nxt.r = r2;
-				if (ch + 2 * kEmitWaves < nchunks)
-					r2 = fetch_record(R, (ch + 2 * kEmitWaves) * 64, cn(ch + 2 * kEmitWaves), lane);
-				if (ch + kEmitWaves < nchunks)
-					fetch_literal(nxt, cn(ch + kEmitWaves), src, avail, lane);
-				(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + chunk_base[ch], stage_all[wv], lane);
-			}
-		}
-		pos = chunk_base[nchunks];
-		__syncthreads();
 	}
-	if (tid == 0)
+	if (lane == 0)
 		A.out_len[blk] = pos;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blocks(CompressArgs A)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	EmitFrag F;
+	if (!emit_frag_setup(A, F))
+		return;
+	const uint8_t *src = A.in + A.in_off[F.blk] + F.fi * kFragment;
+	const uint32_t avail = F.len - F.fi * kFragment;
+	uint8_t *dst = A.out + A.out_off[F.blk];
+	const uint32_t cnt = F.cnt, nchunks = F.nchunks;
+	const uint2 *R = F.R;
+	/* every wave encodes its chunks at their final place (records fetched two of its chunks
+	 * ahead, literal bytes one ahead) */
+#if CSNAPPY_EMIT_PROF
+	unsigned long long ept[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	const unsigned long long ept_begin = __builtin_amdgcn_s_memtime();
+#endif
+	ChunkIn cur, nxt;
+	auto cn = [&](uint32_t ch) { return min(64u, cnt - ch * 64); };
+	uint2 r2 = make_uint2(0, 0);
+	if (wv < nchunks) {
+		nxt.r = fetch_record(R, wv * 64, cn(wv), lane);
+		if (wv + kEmitWaves < nchunks)
+			r2 = fetch_record(R, (wv + kEmitWaves) * 64, cn(wv + kEmitWaves), lane);
+		fetch_literal(nxt, cn(wv), src, avail, lane);
+	}
+	for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
+		cur = nxt;
+		nxt.r = r2;
+		if (ch + 2 * kEmitWaves < nchunks)
+			r2 = fetch_record(R, (ch + 2 * kEmitWaves) * 64, cn(ch + 2 * kEmitWaves), lane);
+		if (ch + kEmitWaves < nchunks)
+			fetch_literal(nxt, cn(ch + kEmitWaves), src, avail, lane);
+#if CSNAPPY_EMIT_PROF
+		(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + F.base[ch], stage_all[wv], lane, ept);
+#else
+		(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + F.base[ch], stage_all[wv], lane);
+#endif
+	}
+#if CSNAPPY_EMIT_PROF
+	if (lane == 0) {
+		atomicAdd(&g_emit_prof[0], __builtin_amdgcn_s_memtime() - ept_begin);
+		for (int k = 0; k < 5; ++k)
+			atomicAdd(&g_emit_prof[1 + k], ept[k]);
+		atomicAdd(&g_emit_prof[8], ept[7]);
+		atomicAdd(&g_emit_prof[9], 1ull);
+	}
+#endif
 }
 
 /* ==========================================================================================
@@ -2960,6 +3083,17 @@ void csnappy_hip_debug_set_profile_buffer(void *d_buf)
 	g_prof_buf = static_cast<unsigned long long *>(d_buf);
 }
 
+#if CSNAPPY_EMIT_PROF
+/* development builds only: read (and clear) the emit kernel's phase counters */
+int csnappy_hip_debug_emit_prof(unsigned long long *out16)
+{
+	static const unsigned long long zero[16] = { 0 };
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_emit_prof), sizeof(zero)) != hipSuccess)
+		return -1;
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #if CSNAPPY_DEC_PROF
 /* development builds only: read (and clear) the decompress kernel's phase counters */
 int csnappy_hip_debug_dec_prof(unsigned long long *out32)
@@ -3120,8 +3254,11 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		if (A.emit_wave_per_block)
 			hipLaunchKernelGGL(snappy_emit_pages, dim3((nb + kEmitWaves - 1) / kEmitWaves), dim3(64 * kEmitWaves), 0,
 					   st, A);
-		else
-			hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb), dim3(64 * kEmitWaves), 0, st, A);
+		else {
+			hipLaunchKernelGGL(snappy_emit_sizes, dim3(nb * fpb), dim3(64 * kEmitWaves), 0, st, A);
+			hipLaunchKernelGGL(snappy_emit_bases, dim3(nb), dim3(64), 0, st, A);
+			hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb * fpb), dim3(64 * kEmitWaves), 0, st, A);
+		}
 		t.stop(1);
 		if (!hip_ok(hipGetLastError(), "launch snappy_emit_blocks"))
 			return CSNAPPY_HIP_E_RUNTIME;
