@@ -1367,7 +1367,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 
 constexpr uint32_t kEmitWaves = 4;
 constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records): their totals fit the first 1 KiB of its id region */
-static_assert(kMaxChunks * 4 <= 1024, "chunk totals live in the smallest id region");
+static_assert(kMaxChunks <= 254, "chunk offsets + two words live in the smallest id region (1 KiB)");
 
 /* small blocks (pages): one wave per block, chunks in order, no size pass.  (A kernel of its own:
  * inlined beside the workgroup-per-block path below, the two copies of emit_chunk cost the
@@ -1428,26 +1428,29 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pag
 	return;
 }
 
-/* Blocks of more than 8 KiB: three launches over the chunk of the batch, no barrier anywhere.
+/* Blocks of more than 8 KiB: three launches over the chunk of the batch.
  *   snappy_emit_sizes   one workgroup per FRAGMENT: the encoded bytes of each of its 64-record
- *                       chunks (the parser's id / table region of the fragment is free by now and
- *                       takes the <= 129 totals)
- *   snappy_emit_bases   one wave per BLOCK: the length prefix, then the totals of its fragments'
- *                       chunks, in order, turned into their offsets in the block's slot
- *                       (fragment k+1 starts where fragment k ended, :647-653); out_len
+ *                       chunks, turned into the chunks' offsets inside the fragment's output, and
+ *                       the fragment's total (the parser's id / table region of the fragment is
+ *                       free by now and takes the <= 129 + 2 words)
+ *   snappy_emit_bases   one wave per BLOCK: the length prefix, then the fragments' totals turned
+ *                       into their offsets in the block's slot, 64 fragments per step (fragment
+ *                       k+1 starts where fragment k ended, :647-653); out_len
  *   snappy_emit_blocks  one workgroup per FRAGMENT: every wave encodes its 64-record chunks at
- *                       their final place
+ *                       their final place, no barrier
  * (Until round 3 one workgroup did all of this for a whole block, fragment after fragment, with
  * three barriers per fragment: a block's waves waited for each other, and a long single stream
  * was emitted by one workgroup.) */
 struct EmitFrag {
 	uint32_t blk, fi, len, cnt, nchunks;
 	const uint2 *R;
-	uint32_t *base; /* per 64-record chunk: encoded bytes (after snappy_emit_sizes), then offset in the block's slot */
+	uint32_t *base; /* per 64-record chunk: its offset in the fragment's output; [kFragTotal] the fragment's
+			 * encoded bytes, [kFragBase] its offset in the block's slot (snappy_emit_bases) */
 };
+constexpr uint32_t kFragTotal = 254, kFragBase = 255; /* (words of the fragment's 1 KiB: kMaxChunks <= 254) */
 
 /* false: the fragment does not exist, or its block cannot be emitted (snappy_emit_bases reports it) */
-DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F)
+DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F, bool after_bases)
 {
 	const uint32_t c = blockIdx.x;
 	F.blk = A.blk_base + c / A.fpb;
@@ -1461,6 +1464,9 @@ DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F)
 	F.cnt = A.rec_cnt[c];
 	if (F.cnt >= kWantGlobal)
 		return false;
+	/* (a block with an unparsed fragment: snappy_emit_bases said so and laid nothing out) */
+	if (after_bases && A.out_len[F.blk] == 0xffffffffu)
+		return false;
 	F.nchunks = (F.cnt + 63) >> 6;
 	F.R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)c * A.rec_cap);
 	F.base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)c * A.tab_stride);
@@ -1469,9 +1475,10 @@ DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F)
 
 extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_sizes(CompressArgs A)
 {
+	__shared__ uint32_t chunk_tot[kMaxChunks];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	EmitFrag F;
-	if (!emit_frag_setup(A, F))
+	if (!emit_frag_setup(A, F, false))
 		return;
 	/* encoded bytes of every 64-record chunk (four chunks' records in flight) */
 	for (uint32_t c0 = wv; c0 < F.nchunks; c0 += 4 * kEmitWaves) {
@@ -1489,9 +1496,25 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_sizes(
 				uint32_t total;
 				(void)wave_excl_scan(f.mine, lane, &total);
 				if (lane == 0)
-					F.base[ch] = total;
+					chunk_tot[ch] = total;
 			}
 		}
+	}
+	__syncthreads();
+	if (wv == 0) {
+		/* exclusive scan of the chunk totals (<= 129 entries) */
+		uint32_t run = 0;
+		for (uint32_t b0 = 0; b0 < F.nchunks; b0 += 64) {
+			const uint32_t ch = b0 + lane;
+			const uint32_t v = ch < F.nchunks ? chunk_tot[ch] : 0;
+			uint32_t total;
+			const uint32_t ex = wave_excl_scan(v, lane, &total);
+			if (ch < F.nchunks)
+				F.base[ch] = run + ex;
+			run += total;
+		}
+		if (lane == 0)
+			F.base[kFragTotal] = run;
 	}
 }
 
@@ -1524,20 +1547,16 @@ extern "C" __global__ void __launch_bounds__(64) snappy_emit_bases(CompressArgs 
 		if (lane < pos)
 			dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
 	}
-	for (uint32_t fi = 0; fi < nfr; ++fi) {
-		const uint32_t c = blockIdx.x * A.fpb + fi;
-		const uint32_t nchunks = (A.rec_cnt[c] + 63) >> 6;
-		uint32_t *base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)c * A.tab_stride);
-		/* exclusive scan of the chunk totals (<= 129 entries) */
-		for (uint32_t b0 = 0; b0 < nchunks; b0 += 64) {
-			const uint32_t ch = b0 + lane;
-			const uint32_t v = ch < nchunks ? base[ch] : 0;
-			uint32_t total;
-			const uint32_t ex = wave_excl_scan(v, lane, &total);
-			if (ch < nchunks)
-				base[ch] = pos + ex;
-			pos += total;
-		}
+	/* exclusive scan of the fragments' totals, 64 fragments per step */
+	for (uint32_t f0 = 0; f0 < nfr; f0 += 64) {
+		const uint32_t fi = f0 + lane;
+		uint32_t *base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)(blockIdx.x * A.fpb + min(fi, nfr - 1)) * A.tab_stride);
+		const uint32_t v = fi < nfr ? base[kFragTotal] : 0;
+		uint32_t total;
+		const uint32_t ex = wave_excl_scan(v, lane, &total);
+		if (fi < nfr)
+			base[kFragBase] = pos + ex;
+		pos += total;
 	}
 	if (lane == 0)
 		A.out_len[blk] = pos;
@@ -1548,11 +1567,11 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	EmitFrag F;
-	if (!emit_frag_setup(A, F))
+	if (!emit_frag_setup(A, F, true))
 		return;
 	const uint8_t *src = A.in + A.in_off[F.blk] + F.fi * kFragment;
 	const uint32_t avail = F.len - F.fi * kFragment;
-	uint8_t *dst = A.out + A.out_off[F.blk];
+	uint8_t *dst = A.out + A.out_off[F.blk] + F.base[kFragBase];
 	const uint32_t cnt = F.cnt, nchunks = F.nchunks;
 	const uint2 *R = F.R;
 	/* every wave encodes its chunks at their final place (records fetched two of its chunks
