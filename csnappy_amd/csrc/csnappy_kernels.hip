@@ -267,7 +267,8 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  *                step ends at its first match.
  * ======================================================================================== */
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
-constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging */
+constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging (but see kMediumLiteral) */
+constexpr uint32_t kMediumLiteral = 256; /* longest literal staged by the wave for its lane */
 constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
@@ -1203,9 +1204,14 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	const uint32_t lhdr = f.lhdr, mine = f.mine;
 	const CopyPlan cp = f.cp;
 	const bool small = record_is_small(f, live, avail);
-	uint64_t bigmask = ballot64(live && !small);
 	uint32_t total;
 	const uint32_t excl = wave_excl_scan(mine, lane, &total);
+	/* A record with a literal of 32..kMediumLiteral bytes (text: one in 150, but it used to split
+	 * its chunk in two stagings and two drains) is staged like a small one when the whole chunk
+	 * fits the staging: its header and tags by its lane, its literal's bytes by the wave. */
+	const bool medium = live && !small && total <= 64 * kBigRecord && lit_len <= kMediumLiteral && cp.bytes <= 16;
+	const uint64_t medmask = ballot64(medium);
+	uint64_t bigmask = ballot64(live && !small && !medium);
 	const uint32_t lw[8] = { in.la.x, in.la.y, in.la.z, in.la.w, in.lb.x, in.lb.y, in.lb.z, in.lb.w };
 	uint32_t seg_lo = 0; /* first record of the current run of small records */
 #if CSNAPPY_EMIT_PROF
@@ -1225,12 +1231,35 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 			 * first byte of the next record -- always a tag byte -- and both are written below */
 #pragma unroll
 			for (uint32_t k = 0; k < 8; ++k) {
-				if (!ballot64(in_run && 4 * k < lit_len))
+				if (!ballot64(in_run && small && 4 * k < lit_len))
 					break;
-				if (in_run && 4 * k < lit_len)
+				if (in_run && small && 4 * k < lit_len)
 					__builtin_memcpy(o + lhdr + 4 * k, &lw[k], 4);
 			}
 			wave_lds_fence();
+			{
+				const uint64_t run_mask = (seg_hi < 64 ? (1ull << seg_hi) - 1 : ~0ull) & ~((1ull << seg_lo) - 1);
+				uint64_t mm = medmask & run_mask;
+				if (mm) {
+					do {
+						const uint32_t m = first_lane(mm);
+						mm &= mm - 1;
+						const uint32_t ls = rdlane(lit_start, m), ll = rdlane(lit_len, m);
+						uint8_t *pd = stage + sa + fill + (rdlane(excl, m) - run_base) + rdlane(lhdr, m);
+						for (uint32_t j = 4 * lane; j < ll; j += 256) {
+							if (j + 4 <= ll) {
+								uint32_t w;
+								__builtin_memcpy(&w, src + ls + j, 4);
+								__builtin_memcpy(pd + j, &w, 4);
+							} else {
+								for (uint32_t t = j; t < ll; ++t)
+									pd[t] = src[ls + t];
+							}
+						}
+					} while (mm);
+					wave_lds_fence();
+				}
+			}
 			EMIT_TICK(1); /* literal payload into the staging */
 			if (in_run) {
 				if (lhdr == 1) {
