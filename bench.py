@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path over one batch that is already resident in HBM:
-compress every block of the batch (snappy_parse_fragments + snappy_emit_blocks), then
+compress every block of the batch (snappy_parse_fragments + the snappy_emit_* launches), then
 decompress every block back (snappy_decompress_blocks).  The default workload is BASELINE.json
 configs[1]: 1 GiB of the G_text synthetic per GPU, cut into 65536-byte blocks, STREAM mode
 (csnappy_compress / csnappy_decompress semantics), table power 16.  Blocks are independent, so

@@ -6,7 +6,8 @@
  *                               Hash/HashBytes                              :228-236
  *                               FindMatchLength                             :252-295
  *                               fragment loop + table-size pick             :636-654
- *   snappy_emit_blocks          EmitLiteral / EmitCopy(LessThan64)          :332-415
+ *   snappy_emit_sizes/_bases/_blocks, snappy_emit_pages
+ *                               EmitLiteral / EmitCopy(LessThan64)          :332-415
  *                               encode_varint32 + the `compressed = p` chain :46-73, :633-651
  *   snappy_decompress_blocks    csnappy_decompress_noheader                 csnappy_decompress.c:319-387
  *                               SAW__Append* / IncrementalCopy*             :200-317
@@ -230,10 +231,10 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 }
 
 /* ==========================================================================================
- * COMPRESS, kernel 1 of 2: snappy_parse_fragments -- ONE wave per 32 KiB fragment
+ * COMPRESS, part 1 of 2: snappy_parse_fragments -- ONE wave per 32 KiB fragment
  *
  * The wave reproduces the reference's sequential probe loop exactly (csnappy_compress.c:469-606)
- * and writes what it decided as 8-byte (literal, copy) records to HBM; snappy_emit_blocks turns
+ * and writes what it decided as 8-byte (literal, copy) records to HBM; the emit launches turn
  * the records into bytes.  The parser is one dependent chain per fragment, so throughput is
  * (fragments in flight per CU) / (latency of a step): everything here is about keeping the
  * per-fragment LDS footprint and the step short.
@@ -1083,13 +1084,13 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense
 }
 
 /* ==========================================================================================
- * COMPRESS, kernel 2 of 2: snappy_emit_blocks -- one workgroup (4 waves) per block
+ * COMPRESS, part 2 of 2: the emit launches (snappy_emit_sizes / _bases / _blocks; _pages)
  *
- * Turns the parser's records into the block's bytes: EmitLiteral / EmitCopy
+ * Turn the parser's records into the block's bytes: EmitLiteral / EmitCopy
  * (csnappy_compress.c:332-415), the varint length prefix (:46-73) and the pointer chain that
- * puts fragment k+1 behind fragment k (:647-653).  Per fragment: the encoded size of every
- * record (one pass, 64 records per wave), a scan of the per-64-record totals, then every wave
- * encodes its 64-record chunks into its own LDS staging and flushes them with aligned
+ * puts fragment k+1 behind fragment k (:647-653).  The encoded size of every record (one pass,
+ * 64 records per wave), a scan of the per-64-record totals and of the fragments' totals, then
+ * every wave encodes its 64-record chunks into its own LDS staging and flushes them with aligned
  * 16 B/lane stores at the chunk's final place in the block's slot -- nothing is moved twice.
  * ======================================================================================== */
 struct RecFields {

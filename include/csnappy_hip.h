@@ -160,7 +160,7 @@ void csnappy_hip_gather_layout(const uint64_t *rank_bytes, uint32_t nranks, uint
  * `stream` around each kernel (nothing synchronises in the launch path).
  * csnappy_hip_get_kernel_timing() waits for the recorded events, returns the summed duration
  * (milliseconds) and the number of launches per kernel since the previous read, and resets.
- * slots: [0] snappy_parse_fragments (all its launches)  [1] snappy_emit_blocks  [2] snappy_decompress_blocks
+ * slots: [0] snappy_parse_fragments (all its launches)  [1] the emit launches (snappy_emit_*)  [2] snappy_decompress_blocks
  *        [3] the stream call's index kernels (snappy_stream_*), one count per call
  */
 void csnappy_hip_set_kernel_timing(int enable);
