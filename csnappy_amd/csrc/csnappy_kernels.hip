@@ -1223,6 +1223,12 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
 		if (seg_hi > seg_lo) {
 			/* stage small records [seg_lo, seg_hi) */
+			/* (opaque copies: the loop runs once unless the chunk has a big record, and the
+			 * compiler otherwise evaluates every predicate of this block -- a dozen 64-bit lane
+			 * masks -- in front of the loop and spills them to a VGPR's lanes) */
+			uint32_t lit_len_ = lit_len, lhdr_ = lhdr, clen_ = clen, coff_ = coff;
+			uint32_t k64_ = cp.k64, k60_ = cp.k60, last_ = cp.last;
+			asm volatile("" : "+v"(lit_len_), "+v"(lhdr_), "+v"(clen_), "+v"(coff_), "+v"(k64_), "+v"(k60_), "+v"(last_));
 			const uint32_t run_base = rdlane(excl, seg_lo);
 			const uint32_t run_bytes = (seg_hi < 64 ? rdlane(excl, seg_hi & 63) : total) - run_base;
 			const bool in_run = lane >= seg_lo && lane < seg_hi;
@@ -1230,12 +1236,18 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 			/* literal payload first, as whole dwords (unaligned LDS stores): the up to three
 			 * bytes a lane writes past its literal land on its own copy tag and, at most, on the
 			 * first byte of the next record -- always a tag byte -- and both are written below */
+			{
+				/* (left = the lane's payload bytes still to store; kept opaque to the compiler, which
+				 * otherwise computes the eight rounds' lane masks up front and spills them) */
+				uint32_t left = in_run && small ? lit_len_ : 0;
 #pragma unroll
-			for (uint32_t k = 0; k < 8; ++k) {
-				if (!ballot64(in_run && small && 4 * k < lit_len))
-					break;
-				if (in_run && small && 4 * k < lit_len)
-					__builtin_memcpy(o + lhdr + 4 * k, &lw[k], 4);
+				for (uint32_t k = 0; k < 8; ++k) {
+					asm volatile("" : "+v"(left));
+					if (!ballot64(left > 4 * k))
+						break;
+					if (left > 4 * k)
+						__builtin_memcpy(o + lhdr_ + 4 * k, &lw[k], 4);
+				}
 			}
 			wave_lds_fence();
 			{
@@ -1245,8 +1257,8 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 					do {
 						const uint32_t m = first_lane(mm);
 						mm &= mm - 1;
-						const uint32_t ls = rdlane(lit_start, m), ll = rdlane(lit_len, m);
-						uint8_t *pd = stage + sa + fill + (rdlane(excl, m) - run_base) + rdlane(lhdr, m);
+						const uint32_t ls = rdlane(lit_start, m), ll = rdlane(lit_len_, m);
+						uint8_t *pd = stage + sa + fill + (rdlane(excl, m) - run_base) + rdlane(lhdr_, m);
 						for (uint32_t j = 4 * lane; j < ll; j += 256) {
 							if (j + 4 <= ll) {
 								uint32_t w;
@@ -1263,33 +1275,33 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 			}
 			EMIT_TICK(1); /* literal payload into the staging */
 			if (in_run) {
-				if (lhdr == 1) {
-					o[0] = (uint8_t)((lit_len - 1) << 2);
-				} else if (lhdr == 2) {
+				if (lhdr_ == 1) {
+					o[0] = (uint8_t)((lit_len_ - 1) << 2);
+				} else if (lhdr_ == 2) {
 					o[0] = (uint8_t)(60 << 2);
-					o[1] = (uint8_t)(lit_len - 1);
+					o[1] = (uint8_t)(lit_len_ - 1);
 				}
 			}
-			if (in_run && clen) {
-				uint8_t *q = o + lhdr + lit_len;
-				const uint8_t lo = (uint8_t)(coff & 0xff), hi = (uint8_t)(coff >> 8);
-				for (uint32_t k = 0; k < cp.k64; ++k) {
+			if (in_run && clen_) {
+				uint8_t *q = o + lhdr_ + lit_len_;
+				const uint8_t lo = (uint8_t)(coff_ & 0xff), hi = (uint8_t)(coff_ >> 8);
+				for (uint32_t k = 0; k < k64_; ++k) {
 					q[0] = 0xfe; /* COPY_2 | (63 << 2) */
 					q[1] = lo;
 					q[2] = hi;
 					q += 3;
 				}
-				if (cp.k60) {
+				if (k60_) {
 					q[0] = 0xee; /* COPY_2 | (59 << 2) */
 					q[1] = lo;
 					q[2] = hi;
 					q += 3;
 				}
-				if (cp.last < 12 && coff < 2048) {
-					q[0] = (uint8_t)(1 + ((cp.last - 4) << 2) + ((coff >> 8) << 5));
+				if (last_ < 12 && coff_ < 2048) {
+					q[0] = (uint8_t)(1 + ((last_ - 4) << 2) + ((coff_ >> 8) << 5));
 					q[1] = lo;
 				} else {
-					q[0] = (uint8_t)(2 + ((cp.last - 1) << 2));
+					q[0] = (uint8_t)(2 + ((last_ - 1) << 2));
 					q[1] = lo;
 					q[2] = hi;
 				}
