@@ -339,9 +339,16 @@ def run(args, eng, dist, rank, world):
     # the one collective of the path: the final stream to rank 0 (throughput is reported
     # both without and with it).  On by default as soon as there is more than one rank.
     gather = None
+    gather_error = None
     want_gather = args.gather if args.gather is not None else world > 1
     if want_gather and dist is not None:
-        gather = eng.time_gather(d_out, b, dist, world)  # the last chunk's output
+        # (outside the timed region; a collective that fails must not cost the run its throughput line.
+        # Every rank takes the same path: either all of them enter the collective or none does.)
+        try:
+            gather = eng.time_gather(d_out, b, dist, world)  # the last chunk's output
+        except Exception as e:  # noqa: BLE001 -- reported in the record, the measurement stands
+            gather = None
+            gather_error = f"{type(e).__name__}: {e}"[:200]
 
     if rank != 0:
         return None
@@ -400,6 +407,8 @@ def run(args, eng, dist, rank, world):
         "kernels": kernels,
         "roofline": roofline,
     }
+    if gather_error is not None:
+        out["gather_error"] = gather_error
     if gather is not None:
         # the same round trip with the gather of the final stream added to every step's time
         # (the last chunk's stream stands for the step's: one chunk in the default workload)
