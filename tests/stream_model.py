@@ -86,7 +86,8 @@ def build_index(body):
 
 
 def chain(body, esz, segs):
-    """snappy_stream_chain: where the true parse enters and leaves every segment."""
+    """The chain, sequentially (what snappy_stream_chain_groups / _link must reproduce): where the
+    true parse enters and leaves every segment."""
     n = len(body)
     e = 0
     entry, leave = [], []
@@ -107,6 +108,58 @@ def chain(body, esz, segs):
             e = min(lt + int(esz[lt]), 0xFFFFFFFF)
         leave.append(e)
     return entry, leave, e
+
+
+def chain_step(body, esz, seg, k, e):
+    """one segment of the chain: -> (entry or NO_ENTRY, leave, e afterwards)"""
+    n = len(body)
+    spec, spec_leave, last, safe = seg
+    lo, hi = k * SEG, min((k + 1) * SEG, n)
+    if e >= hi:
+        return NO_ENTRY, 0, e
+    ent = e
+    after = e + int(esz[e]) if e < n else e + 2
+    if after >= hi:
+        e = min(after, 0xFFFFFFFF)
+    elif e - lo < safe:
+        e = spec_leave
+    else:
+        lt = lo + int(last[e - lo])
+        e = min(lt + int(esz[lt]), 0xFFFFFFFF)
+    return ent, e, e
+
+
+def chain_in_groups(body, esz, segs, group=64):
+    """snappy_stream_chain_groups + snappy_stream_chain_link: every group of `group` segments is
+    walked on the ASSUMPTION that the parse enters its first segment inside the safe prefix with an
+    element that stays inside the segment (then it leaves that segment with the speculative parse
+    whatever the entry was); one pass then links the groups and walks those again whose assumption
+    does not hold.  -> (entry, leave, end, groups walked again): the first three must equal chain()'s."""
+    n = len(body)
+    nseg = len(segs)
+    entry, leave = [NO_ENTRY] * nseg, [0] * nseg
+    exits = []
+    for g0 in range(0, nseg, group):                           # step 1: all groups "at once"
+        if g0 == 0:
+            e, first = 0, 0
+        else:
+            e, first = segs[g0][1], g0 + 1                     # leaves the first segment with the speculative parse
+            leave[g0] = e
+        for k in range(first, min(g0 + group, nseg)):
+            entry[k], leave[k], e = chain_step(body, esz, segs[k], k, e)
+        exits.append(e)
+    e, redone = exits[0], 0
+    for gi, g0 in enumerate(range(group, nseg, group), start=1):  # step 2: the link
+        lo, hi = g0 * SEG, min((g0 + 1) * SEG, n)
+        after = e + int(esz[e]) if e < n else e + 2
+        if lo <= e < hi and after < hi and e - lo < segs[g0][3]:
+            entry[g0] = e
+            e = exits[gi]
+        else:
+            redone += 1
+            for k in range(g0, min(g0 + group, nseg)):
+                entry[k], leave[k], e = chain_step(body, esz, segs[k], k, e)
+    return entry, leave, e, redone
 
 
 def settle(esz, l, n, k, entry, spec):

@@ -100,6 +100,33 @@ def test_index_is_exact_on_damaged_and_foreign_bodies():
         assert got["end"] == end and got["total"] == total and got["starts"] == starts
 
 
+def test_chain_in_groups_equals_the_sequential_chain():
+    """snappy_stream_chain_groups / _link: groups walked on an assumed entry, linked, re-walked where
+    the assumption fails -- same entries, leaves and end as the one-pass chain; with small groups on
+    text (the assumption mostly holds), literal-heavy and damaged bodies (it mostly does not)."""
+    rng = np.random.default_rng(31)
+    good, _ = _body(oracle.Port().compress(_mixed(4, 400000), 16))
+    text, _ = _body(oracle.Port().compress(bytes(api.generate_host(0, 0xC5A90001, 0, 8, 65536)), 16))
+    bodies = [good, text, good[:len(good) - 33], bytes(rng.integers(0, 256, 70000, dtype=np.uint8))]
+    for _ in range(4):
+        m = bytearray(good)
+        m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        at = int(rng.integers(0, len(m)))
+        m[at:at] = bytes.fromhex(["f4ffff", "fe0090"][int(rng.integers(0, 2))])
+        bodies.append(bytes(m))
+    kept = redone = 0
+    for body in bodies:
+        esz, l, segs = sm.build_index(body)
+        want = sm.chain(body, esz, segs)
+        for group in (2, 5, 64):
+            entry, leave, end, again = sm.chain_in_groups(body, esz, segs, group)
+            assert (entry, leave, end) == want, (len(body), group)
+            ngroups = (len(segs) + group - 1) // group
+            redone += again
+            kept += max(ngroups - 1, 0) - again
+    assert kept > 0 and redone > 0  # both outcomes of the link are exercised
+
+
 def test_tags_at_matches_the_reference_char_table_semantics():
     """every tag byte with a fixed trailer: element sizes as csnappy_decompress.c:152-185 / :348-365"""
     trailer = bytes([0x11, 0x22, 0x33, 0x44, 0x55, 0, 0, 0])
