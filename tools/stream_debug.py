@@ -15,9 +15,10 @@ def layout(n, ulen):
     for name, size in (("tagmask", nseg * 512), ("winout", nseg * 256), ("truemask", nseg * 512), ("trueout", nseg * 256),
                        ("seg_out", nseg * 8), ("seg_exit", nseg * 4), ("seg_xesz", nseg * 4), ("seg_safe", nseg * 4),
                        ("seg_leave", nseg * 4), ("last_tag", nseg * 8192), ("seg_entry", nseg * 4),
+                       ("grp_e", ((nseg + 63) // 64) * 4), ("grp_esz", ((nseg + 63) // 64) * 4),
                        ("f_in_off", nfrag * 8), ("f_out_off", nfrag * 8), ("frag_pos", nfrag * 4),
                        ("f_in_len", nfrag * 4), ("f_out_cap", nfrag * 4), ("f_produced", nfrag * 4), ("f_status", nfrag * 4),
-                       ("one_off", 16), ("total", 8), ("one_len", 8), ("flags", 16)):
+                       ("one_off", 16), ("total", 8), ("one_len", 8), ("flags", 32)):
         out[name] = (at, size)
         at += (size + 15) & ~15
     return out, at, nseg, nfrag
