@@ -1589,16 +1589,26 @@ extern "C" __global__ void __launch_bounds__(64) snappy_emit_bases(CompressArgs 
 		if (lane < pos)
 			dst[lane] = (uint8_t)((len >> (7 * lane)) | (lane + 1 < pos ? 0x80u : 0u));
 	}
-	/* exclusive scan of the fragments' totals, 64 fragments per step */
-	for (uint32_t f0 = 0; f0 < nfr; f0 += 64) {
-		const uint32_t fi = f0 + lane;
-		uint32_t *base = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)(blockIdx.x * A.fpb + min(fi, nfr - 1)) * A.tab_stride);
-		const uint32_t v = fi < nfr ? base[kFragTotal] : 0;
-		uint32_t total;
-		const uint32_t ex = wave_excl_scan(v, lane, &total);
-		if (fi < nfr)
-			base[kFragBase] = pos + ex;
-		pos += total;
+	/* exclusive scan of the fragments' totals, 64 fragments per step, the loads of four steps in
+	 * flight (they are 64 KiB apart: every step is a round trip to HBM) */
+	for (uint32_t f0 = 0; f0 < nfr; f0 += 256) {
+		uint32_t *base[4];
+		uint32_t v[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4; ++u) {
+			const uint32_t fi = f0 + 64 * u + lane;
+			base[u] = reinterpret_cast<uint32_t *>(A.tabs + (uint64_t)(blockIdx.x * A.fpb + min(fi, nfr - 1)) * A.tab_stride);
+			v[u] = fi < nfr ? base[u][kFragTotal] : 0;
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < 4; ++u) {
+			const uint32_t fi = f0 + 64 * u + lane;
+			uint32_t total;
+			const uint32_t ex = wave_excl_scan(v[u], lane, &total);
+			if (fi < nfr)
+				base[u][kFragBase] = pos + ex;
+			pos += total;
+		}
 	}
 	if (lane == 0)
 		A.out_len[blk] = pos;
