@@ -1161,8 +1161,16 @@ __device__ unsigned long long g_emit_prof[16];
 #define EMIT_TICK(k) do { } while (0)
 #define EMIT_PROF_ARG
 #endif
+/* what a wave's staging holds between chunks: consecutive chunks of a wave are consecutive in the
+ * output, so the staging is drained when the next chunk would not fit it (and behind the wave's
+ * last chunk), not behind every chunk */
+struct EmitState {
+	uint32_t gpos; /* output bytes already in HBM (relative to dst) */
+	uint32_t fill; /* staged bytes */
+};
+
 DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, const uint8_t *src, uint32_t avail,
-			   uint8_t *dst, uint8_t *stage, uint32_t lane EMIT_PROF_ARG)
+			   uint8_t *dst, uint8_t *stage, uint32_t lane, EmitState &st, bool last_chunk EMIT_PROF_ARG)
 {
 #if CSNAPPY_EMIT_PROF
 	unsigned long long ept_last = __builtin_amdgcn_s_memtime();
@@ -1170,8 +1178,8 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 #endif
 	/* staged byte t (t < fill) is output byte gpos + t and sits at stage[sa + t], where
 	 * sa = (dst + gpos) & 15, so LDS 16 B chunks line up with global 16 B chunks. */
-	uint32_t gpos = 0, fill = 0;
-	uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+	uint32_t gpos = st.gpos, fill = st.fill;
+	uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + gpos) & 15u);
 
 	auto drain = [&]() {
 		wave_lds_fence();
@@ -1219,6 +1227,8 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	asm volatile("" : : "v"(excl), "v"(lw[0]), "v"(lw[7]));
 #endif
 	EMIT_TICK(0); /* decode, offsets (and the wait for the chunk's own loads) */
+	if (fill && fill + total > 64 * kBigRecord)
+		drain(); /* (a chunk with a big record may exceed the staging by itself: its runs do not) */
 	while (nev) {
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
 		if (seg_hi > seg_lo) {
@@ -1402,9 +1412,12 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 		seg_lo = e + 1;
 		EMIT_TICK(3); /* a big record */
 	}
-	drain();
+	if (last_chunk)
+		drain();
 	EMIT_TICK(4); /* drain */
-	return gpos;
+	st.gpos = gpos;
+	st.fill = fill;
+	return total;
 }
 
 constexpr uint32_t kEmitWaves = 4;
@@ -1451,6 +1464,8 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pag
 	uint2 r2 = cnt > 64 ? fetch_record(R, 64, min(64u, cnt - 64), lane) : make_uint2(0, 0);
 	if (cnt)
 		fetch_literal(nxt, min(64u, cnt), src, len, lane);
+	EmitState st = { 0, 0 };
+	uint8_t *body = dst + pos;
 	for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
 		cur = nxt;
 		nxt.r = r2;
@@ -1460,9 +1475,9 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pag
 			fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
 #if CSNAPPY_EMIT_PROF
 		unsigned long long ept_pages[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane, ept_pages);
+		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt, ept_pages);
 #else
-		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, dst + pos, stage_all[wv], lane);
+		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt);
 #endif
 	}
 	if (lane == 0)
@@ -1626,32 +1641,37 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 	uint8_t *dst = A.out + A.out_off[F.blk] + F.base[kFragBase];
 	const uint32_t cnt = F.cnt, nchunks = F.nchunks;
 	const uint2 *R = F.R;
-	/* every wave encodes its chunks at their final place (records fetched two of its chunks
-	 * ahead, literal bytes one ahead) */
+	/* every wave encodes a run of consecutive chunks at their final place (records fetched two
+	 * chunks ahead, literal bytes one ahead); consecutive chunks are consecutive in the output,
+	 * so the wave's staging is drained when it is full, not behind every chunk */
 #if CSNAPPY_EMIT_PROF
 	unsigned long long ept[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	const unsigned long long ept_begin = __builtin_amdgcn_s_memtime();
 #endif
+	const uint32_t per = (nchunks + kEmitWaves - 1) / kEmitWaves;
+	const uint32_t c_lo = min(wv * per, nchunks), c_hi = min(c_lo + per, nchunks);
 	ChunkIn cur, nxt;
 	auto cn = [&](uint32_t ch) { return min(64u, cnt - ch * 64); };
 	uint2 r2 = make_uint2(0, 0);
-	if (wv < nchunks) {
-		nxt.r = fetch_record(R, wv * 64, cn(wv), lane);
-		if (wv + kEmitWaves < nchunks)
-			r2 = fetch_record(R, (wv + kEmitWaves) * 64, cn(wv + kEmitWaves), lane);
-		fetch_literal(nxt, cn(wv), src, avail, lane);
+	if (c_lo < c_hi) {
+		nxt.r = fetch_record(R, c_lo * 64, cn(c_lo), lane);
+		if (c_lo + 1 < c_hi)
+			r2 = fetch_record(R, (c_lo + 1) * 64, cn(c_lo + 1), lane);
+		fetch_literal(nxt, cn(c_lo), src, avail, lane);
 	}
-	for (uint32_t ch = wv; ch < nchunks; ch += kEmitWaves) {
+	EmitState st = { 0, 0 };
+	uint8_t *body = dst + (c_lo < c_hi ? F.base[c_lo] : 0u);
+	for (uint32_t ch = c_lo; ch < c_hi; ++ch) {
 		cur = nxt;
 		nxt.r = r2;
-		if (ch + 2 * kEmitWaves < nchunks)
-			r2 = fetch_record(R, (ch + 2 * kEmitWaves) * 64, cn(ch + 2 * kEmitWaves), lane);
-		if (ch + kEmitWaves < nchunks)
-			fetch_literal(nxt, cn(ch + kEmitWaves), src, avail, lane);
+		if (ch + 2 < c_hi)
+			r2 = fetch_record(R, (ch + 2) * 64, cn(ch + 2), lane);
+		if (ch + 1 < c_hi)
+			fetch_literal(nxt, cn(ch + 1), src, avail, lane);
 #if CSNAPPY_EMIT_PROF
-		(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + F.base[ch], stage_all[wv], lane, ept);
+		(void)emit_chunk(cur, nxt, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi, ept);
 #else
-		(void)emit_chunk(cur, nxt, cn(ch), src, avail, dst + F.base[ch], stage_all[wv], lane);
+		(void)emit_chunk(cur, nxt, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi);
 #endif
 	}
 #if CSNAPPY_EMIT_PROF
