@@ -56,6 +56,15 @@ constexpr uint32_t kFragment = 32768;    /* kBlockSize, csnappy_compress.c:85-86
 constexpr uint32_t kMargin = 15;         /* kInputMarginBytes, csnappy_compress.c:468 */
 constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
 
+#ifndef CSNAPPY_PARSE_NTLOAD
+#define CSNAPPY_PARSE_NTLOAD 1
+#endif
+#ifndef CSNAPPY_PARSE_NOSTORE
+#define CSNAPPY_PARSE_NOSTORE 4
+#endif
+#ifndef CSNAPPY_PARSE_NOSPILLSTORE
+#define CSNAPPY_PARSE_NOSPILLSTORE 0
+#endif
 #define DEVINL __device__ __forceinline__
 
 struct CompressArgs {
@@ -661,7 +670,11 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			uint4 v;
 			__builtin_memcpy(&v, src + pos, 16);
 			/* (the ids are read once: streaming hint, they should not push the window out of L2) */
+#if CSNAPPY_PARSE_NTLOAD
 			const uint16_t idv = DENSE ? __builtin_nontemporal_load(ids + pos) : (uint16_t)kNoBucket;
+#else
+			const uint16_t idv = DENSE ? ids[pos] : (uint16_t)kNoBucket;
+#endif
 			raw0 = v.x;
 			raw1 = v.y;
 			raw2 = v.z;
@@ -671,6 +684,16 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		place();
 
 		uint32_t guard = 0; /* every step probes or inserts at least one new position: a logic error must not hang the GPU */
+#if CSNAPPY_PARSE_NOSTORE == 4
+		/* the previous step's records, stored BEHIND this step's candidate gather: gfx9 counts loads and
+		 * stores in one vmcnt, so a store issued in front of the gather would have to be acknowledged
+		 * before the gather's wait ends.  Every lane stores, the lanes without a record into the last slot
+		 * of the fragment's record region (which no record reaches), so that the number of memory
+		 * instructions behind the gather is the same on every path */
+		uint2 prec = make_uint2(0, 0);
+		uint32_t prec_idx = A.rec_cap - 1;
+#define CSNAPPY_FLUSH_PREC() (*reinterpret_cast<unsigned long long *>(R + prec_idx) = *reinterpret_cast<unsigned long long *>(&prec))
+#endif
 		while (!fin && ++guard <= n) {
 			tick(0); /* (rest of the previous step: commit) */
 			if (PROF) {
@@ -720,6 +743,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			uint4 w4 = make_uint4(0, 0, 0, 0);
 			if (!sparse_c) {
 				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
+#if CSNAPPY_PARSE_NOSTORE == 4
+				CSNAPPY_FLUSH_PREC();
+#endif
 			}
 			const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
 			const bool flagged = tabbed & FT::flags(fe1, fe2, slot, lane);
@@ -752,6 +778,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t ulim = min(c1, v);
 				const bool gathered = lane < ulim && maybe;
 				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
+#if CSNAPPY_PARSE_NOSTORE == 4
+				CSNAPPY_FLUSH_PREC();
+#endif
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
 				const uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
@@ -965,9 +994,21 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
 			if (PROF && sparse_c)
 				pn_sparse++;
+#if CSNAPPY_PARSE_NOSTORE == 4
+			prec = rec;
+			prec_idx = rec_mine ? rec_idx : A.rec_cap - 1;
+#elif CSNAPPY_PARSE_NOSTORE == 2
+			if (rec_mine)
+				R[rec_idx] = rec;
+#elif CSNAPPY_PARSE_NOSTORE == 3
+			/* every lane stores: the lanes without a record into the last slot of the fragment's
+			 * record region, which no record can reach */
+			*reinterpret_cast<unsigned long long *>(R + (rec_mine ? rec_idx : A.rec_cap - 1)) = *reinterpret_cast<unsigned long long *>(&rec);
+#elif !CSNAPPY_PARSE_NOSTORE /* (1: timing experiment only: wrong output) */
 			if (rec_mine)
 				__builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&rec),
 							    reinterpret_cast<unsigned long long *>(R + rec_idx));
+#endif
 			/* commit table[slot] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			bool commit = lane <= e_final && !inside && tabbed;
@@ -998,10 +1039,14 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			} else if (commit && !spilled) {
 				tab[slot] = (uint16_t)(pos_c | (chk << 15));
 			}
-			if (SPILL && commit && spilled)
+			if (!CSNAPPY_PARSE_NOSPILLSTORE && SPILL && commit && spilled) /* (macro: timing experiment only) */
 				spill[slot - dense_cap] = (uint16_t)(pos_c | (chk << 15));
 			wave_lds_fence();
 		}
+#if CSNAPPY_PARSE_NOSTORE == 4
+		CSNAPPY_FLUSH_PREC();
+#undef CSNAPPY_FLUSH_PREC
+#endif
 		stuck = !fin;
 	}
 
@@ -1012,7 +1057,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		++nev;
 	}
 	if (lane == 0)
-		A.rec_cnt[F.c] = stuck ? kNoRecords : nev; /* (never parsed: the emit kernel reports the block as failed) */
+		A.rec_cnt[F.c] = CSNAPPY_PARSE_NOSTORE == 1 ? 0u : stuck ? kNoRecords : nev; /* (never parsed: the emit kernel reports the block as failed) */
 	if (PROF && lane == 0) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 		atomicAdd(&A.prof[0], t_end - pt_begin);
