@@ -412,10 +412,15 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 		for (uint32_t k = lane; k < 256; k += 64)
 			seen1[k] = 0;
 		wave_lds_fence();
+		/* (all 32 samples requested before the first is used: with the atomic behind each load the
+		 * compiler waited for every load on its own, 32 round trips in a row) */
+		uint32_t w[32];
+#pragma unroll
+		for (uint32_t j = 0; j < 32; ++j)
+			__builtin_memcpy(&w[j], src + 16 * lane + 1024 * j, 4);
+#pragma unroll
 		for (uint32_t j = 0; j < 32; ++j) {
-			uint32_t w;
-			__builtin_memcpy(&w, src + 16 * lane + 1024 * j, 4);
-			const uint32_t h = (w * kHashMul) >> 19;
+			const uint32_t h = (w[j] * kHashMul) >> 19;
 			atomicOr(&seen1[h >> 5], 1u << (h & 31));
 		}
 		wave_lds_fence();
