@@ -765,7 +765,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				wave_lds_fence();
 				epoch = FT::kEpochs;
 			}
-			uint32_t touch_a = 0, touch_b = 0;
+			uint32_t touch_b = 0;
 			tick(2); /* filters + table */
 
 			uint32_t e_final;
@@ -818,15 +818,12 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
 				/* behind the gather (loads return in order: in front of it, the gather would wait for
-				 * these too): touch the input and id lines two steps ahead -- the exact cursor is not
-				 * known yet, the lines are -- so that the next place() finds them in the cache
-				 * (text 10.1 -> 9.8 ms per GiB) */
-				{
-					const uint32_t ta = min(p0 + 128 + 4 * lane, n - 4);
-					__builtin_memcpy(&touch_a, src + ta, 4);
-					if (DENSE)
-						touch_b = ids[min(p0 + 128 + 2 * lane, n - 1)];
-				}
+				 * this too): touch the id lines two steps ahead -- the exact cursor is not known yet,
+				 * the lines are -- so that the next place() finds them in the cache (text 10.1 -> 9.8 ms
+				 * per GiB with the input lines touched as well; since the record store moved behind the
+				 * gather the ids alone do as much, 9.00 against 9.05, and none costs 9.14) */
+				if (DENSE)
+					touch_b = ids[min(p0 + 128 + 2 * lane, n - 1)];
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
 				if (PROF) {
@@ -993,7 +990,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
 			 * behind the stores would also sit out the stores' round trip. */
 			tick(7); /* records built */
-			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid) : "v"(touch_a), "v"(touch_b));
+			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid) : "v"(touch_b));
 			if (PROF)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
