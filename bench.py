@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Snappy block-codec hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no launcher around it (no RANK in the environment) bench.py starts the N ranks
+itself, as a child `python -m torch.distributed.run --standalone --nproc-per-node N bench.py ...`,
+and exits with that child's code; under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank.
 
 A "step" is one pass of the hot path over one batch that is already resident in HBM:
 compress every block of the batch (snappy_parse_fragments + the snappy_emit_* launches), then
@@ -222,9 +226,14 @@ class GpuEngine:
     def verify(self, d_in, b, d_out, chunk, block, p, mode, nv):
         return verify_against_reference(self.torch, self.api, d_in, b, d_out, chunk, block, p, mode, nv)
 
-    def time_gather(self, d_out, b, dist, world):
+    def prepare_gather(self, d_out, b, cnt):
+        """The local half of the gather (no collective inside): this rank's compacted stream."""
         from csnappy_amd import shard
-        return shard.time_gather_compacted(d_out, b, dist, world)
+        return shard.compact(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt])[0]
+
+    def time_gather(self, prepared, d_out, b, cnt, dist, world):
+        from csnappy_amd import shard
+        return shard.time_gather_compacted(d_out, b, dist, world, cnt=cnt)
 
 
 def parse_args(argv=None):
@@ -248,6 +257,7 @@ def parse_args(argv=None):
                     help="also time the RCCL gather of the compacted per-rank streams to rank 0 (reported "
                          "separately; never part of `value`).  Default: on when there is more than one rank")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--engine", default=None, help=argparse.SUPPRESS)  # tests: module:Class standing in for GpuEngine
     return ap.parse_args(argv)
 
 
@@ -342,13 +352,21 @@ def run(args, eng, dist, rank, world):
     gather_error = None
     want_gather = args.gather if args.gather is not None else world > 1
     if want_gather and dist is not None:
-        # (outside the timed region; a collective that fails must not cost the run its throughput line.
-        # Every rank takes the same path: either all of them enter the collective or none does.)
+        # (outside the timed region; a gather that fails must not cost the run its throughput line.
+        # The part that can fail on ONE rank -- allocations, the compaction -- runs first and on its own;
+        # the ranks then agree (all_reduce MIN of an ok flag) and enter the exchange together or not at
+        # all: a rank that raised before the collective would otherwise leave the others waiting in it.)
+        prepared, err = None, None
         try:
-            gather = eng.time_gather(d_out, b, dist, world)  # the last chunk's output
+            prepared = eng.prepare_gather(d_out, b, chunks[-1][1])  # the last chunk's output
         except Exception as e:  # noqa: BLE001 -- reported in the record, the measurement stands
-            gather = None
-            gather_error = f"{type(e).__name__}: {e}"[:200]
+            err = f"{type(e).__name__}: {e}"[:200]
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item():
+            gather = eng.time_gather(prepared, d_out, b, chunks[-1][1], dist, world)
+        else:
+            gather_error = err or "another rank could not prepare its stream"
 
     if rank != 0:
         return None
@@ -376,7 +394,10 @@ def run(args, eng, dist, rank, world):
                 "algorithmic_bytes_per_launch": dom_alg // nch,
                 "avg_launch_ms": {k: kernels[k]["avg_ms"] for k in dom_kernels},
                 "operation_ms_per_step": round(op_ms[dom], 4),
-                "launches_per_step": nch, "traffic": traffic}
+                "launches_per_step": nch, "traffic": traffic,
+                # (not measured by this run: PMC counters need rocprofv3 passes of their own)
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC, separate run)" if traffic is not None
+                else None}
 
     gibs = lambda ms: round(n_bytes * world / (ms / 1e3) / 2 ** 30, 3) if ms > 0 else None
     out = {
@@ -413,7 +434,9 @@ def run(args, eng, dist, rank, world):
         # the same round trip with the gather of the final stream added to every step's time
         # (the last chunk's stream stands for the step's: one chunk in the default workload)
         out["gather"] = gather
-        out["value_with_gather"] = round(n_bytes * world / (t_max / args.steps + gather["ms"] / 1e3 * nch) / 2 ** 30, 4)
+        # (scaled by blocks, not by chunks: the last chunk may be a short one)
+        out["value_with_gather"] = round(n_bytes * world / (t_max / args.steps
+                                                            + gather["ms"] / 1e3 * nb / chunks[-1][1]) / 2 ** 30, 4)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(kind, seed, block, p, mode, nb, args.cpu_seconds, urls)
@@ -423,14 +446,40 @@ def run(args, eng, dist, rank, world):
     return out
 
 
-def main():
-    args = parse_args()
+def launch_ranks(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay its output and
+    return its exit code.  Called before anything in this process has touched the GPU, and never
+    an exec: a process that has initialised HIP must not be replaced."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+           "--nnodes=1", f"--nproc-per-node={gpus}", os.path.abspath(__file__)] + list(argv)
+    log("bench.py: starting %d ranks: %s" % (gpus, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC here
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_engine(spec, local_rank):
+    """GpuEngine, or (tests only: --engine module:Class) a stand-in of the same shape."""
+    if not spec:
+        return GpuEngine(local_rank)
+    import importlib
+    mod, _, cls = spec.partition(":")
+    return getattr(importlib.import_module(mod), cls)()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(argv, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    eng = GpuEngine(local_rank)
+    eng = load_engine(args.engine, local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist

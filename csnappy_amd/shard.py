@@ -98,15 +98,17 @@ def gather_lengths(lens, counts, dist, world, group=None):
     return torch.cat([bufs[r][:counts[r]] for r in range(world)])
 
 
-def time_gather_compacted(d_out, b, dist, world, reps=3):
+def time_gather_compacted(d_out, b, dist, world, reps=3, cnt=None):
     """Time compaction + the RCCL gather of the final stream (reported next to, never inside,
-    the codec throughput)."""
+    the codec throughput).  cnt: the blocks of `b` that the last launch filled (a batch's last
+    chunk may be shorter than the descriptors; the lengths behind it are stale)."""
     import torch
+    cnt = len(b.d_out_len) if cnt is None else cnt
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        dense, _ = compact(d_out, b.d_out_off, b.d_out_len)
+        dense, _ = compact(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt])
         _, sizes = gather_to_root(dense, dist, world)
     torch.cuda.synchronize()
     dist.barrier()

@@ -4,10 +4,11 @@ test of the plumbing around it -- block ranges per rank, the slowest-rank reduct
 and per-kernel times, n_ranks_seen, the default-on gather of the compacted streams to rank 0 and
 the record's shape -- so that a first 8-GPU driver run does not die in it)."""
 import hashlib
+import json
 import os
 import socket
+import subprocess
 import sys
-import time
 
 import numpy as np
 import pytest
@@ -19,84 +20,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import bench  # noqa: E402
 import oracle  # noqa: E402
-from csnappy_amd import api, shard  # noqa: E402
+from csnappy_amd import api  # noqa: E402
+
+from tests.cpu_engine import OracleEngine  # noqa: E402
 
 BLOCK, NB = 65536, 24  # blocks per rank
-
-
-class OracleEngine:
-    """Same shape as bench.GpuEngine; tensors live on the CPU, the oracle does the codec work."""
-
-    def __init__(self):
-        self.torch = torch
-        self.device = torch.device("cpu")
-        self.codec = oracle.Port()
-        self.on = False
-        self.ms = {}
-
-    def generate(self, kind, seed, first, nb, block, urls=None):
-        return torch.from_numpy(api.generate_host(kind, seed, first, nb, block).copy())
-
-    def batch(self, lens):
-        return api.Batch(lens, device="cpu")
-
-    def zeros(self, n, dtype):
-        return torch.zeros(n + 64, dtype=dtype)[:n] if dtype == torch.uint8 else torch.zeros(n, dtype=dtype)
-
-    def full(self, n, value, dtype):
-        return torch.full((n,), value, dtype=dtype)
-
-    def _clock(self, name, t0):
-        if self.on:
-            ms, c = self.ms.get(name, (0.0, 0))
-            self.ms[name] = (ms + (time.perf_counter() - t0) * 1e3, c + 1)
-
-    def compress(self, src, b, cnt, d_out, p, mode):
-        t0 = time.perf_counter()
-        _, out_len = oracle.batch_compress(self.codec, src.numpy(), b.in_off[:cnt], b.in_len[:cnt], b.out_off[:cnt],
-                                           d_out.numel() - 64, p, mode, out=d_out.numpy())
-        b.d_out_len[:cnt] = torch.from_numpy(out_len.astype(np.int32))
-        self._clock("snappy_parse_fragments", t0)
-        self._clock("snappy_emit_blocks", time.perf_counter())
-
-    def decompress(self, d_out, b, cnt, d_back, cap, status, produced, mode):
-        t0 = time.perf_counter()
-        lens = b.d_out_len[:cnt].numpy().astype(np.uint32)
-        back = np.zeros(d_back.numel() + 64, dtype=np.uint8)
-        _, st, pr = oracle.batch_decompress(self.codec, d_out.numpy(), b.out_off[:cnt], lens, b.in_off[:cnt],
-                                            cap[:cnt].numpy().astype(np.uint32), d_back.numel(), mode, out=back)
-        d_back[:] = torch.from_numpy(back[:d_back.numel()])
-        status[:cnt] = torch.from_numpy(st)
-        produced[:cnt] = torch.from_numpy(pr.astype(np.int32))
-        self._clock("snappy_decompress_blocks", t0)
-
-    def sync(self):
-        pass
-
-    def timing(self, on):
-        self.on = on
-        if on:
-            self.ms = {}
-
-    def kernel_times(self):
-        return {k: self.ms.get(k, (0.0, 0)) for k in
-                ("snappy_parse_fragments", "snappy_emit_blocks", "snappy_decompress_blocks")}
-
-    def copy_bandwidth(self):
-        return 1.0
-
-    def verify(self, *a):
-        return None
-
-    def time_gather(self, d_out, b, dist_, world):
-        # compact on the host (api.compact_batch is a kernel), then the product's own gather
-        t0 = time.perf_counter()
-        out, lens = d_out.numpy(), b.d_out_len.numpy()
-        dense = torch.from_numpy(np.concatenate([out[int(o):int(o) + int(n)] for o, n in zip(b.out_off, lens)]))
-        rooted, sizes = shard.gather_to_root(dense, dist_, world)
-        self.rooted = rooted
-        return {"ms": round((time.perf_counter() - t0) * 1e3, 3), "gathered_bytes": int(np.sum(sizes)), "GBps": 0.0,
-                "what": "test stand-in"}
 
 
 def _args(world):
@@ -156,3 +84,39 @@ def test_one_rank_without_a_process_group():
     assert rec["n_gpus"] == 1 and rec["n_ranks_seen"] == 1 and "gather" not in rec and rec["vs_baseline"] is None
     assert rec["metric"] == "GiB/s compress+decompress on 64KiB blocks" and rec["unit"] == "GiB/s"
     assert 0.3 < rec["compressed_ratio"] < 0.7
+
+
+def _bench_cli(extra_env=None):
+    """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1 -- no launcher around it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.path.dirname(HERE) + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--gib", str(NB * BLOCK / 2 ** 30), "--no-cpu-baseline", "--verify-gib", "0",
+           "--engine", "tests.cpu_engine:OracleEngine"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no RANK in the environment starts two ranks itself (a child
+    torch.distributed.run; the parent never touches a GPU) and relays rank 0's record."""
+    rec, err = _bench_cli()
+    assert "torch.distributed.run" in err and "--nproc-per-node=2" in err
+    assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2 and rec["value"] > 0
+    assert rec["gather"]["gathered_bytes"] > 0 and "gather_error" not in rec
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_that_cannot_prepare_its_stream_costs_the_gather_not_the_record():
+    """One rank fails in the local half of the gather: the ranks agree not to enter the exchange
+    (nobody is left waiting in a collective) and rank 0 still prints the throughput record."""
+    rec, _ = _bench_cli({"CSNAPPY_TEST_FAIL_PREPARE_ON_RANK": "1"})
+    assert rec["n_ranks_seen"] == 2 and rec["value"] > 0
+    assert "gather" not in rec and "another rank" in rec["gather_error"]
+    rec, _ = _bench_cli({"CSNAPPY_TEST_FAIL_PREPARE_ON_RANK": "0"})
+    assert "gather" not in rec and "MemoryError" in rec["gather_error"]
