@@ -2160,7 +2160,19 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 				wave_lds_fence();
 			}
 			DEC_TICK(8); /* dependent copies */
-			/* ---- flush ---- */
+			/* ---- flush ----
+			 * ORDERING RELIED ON (and not stated by the ISA manual): later batches of this wave load
+			 * bytes these stores write (copy_exact's source `dst + pb - off`, the `dst[op + s]` of a
+			 * dependent copy), and no s_waitcnt sits between the stores and those loads -- vmcnt counts
+			 * a store as done when it is acknowledged, a wait here would cost every batch a memory
+			 * round trip.  What makes the loads see the bytes: all vector-memory instructions of ONE
+			 * wave go through the CU's texture addresser and its L1 (TCP) in issue order; the TCP is
+			 * write-through and a store updates or invalidates the line it hits before a younger access
+			 * of the same wave is looked up, and from the TCP on both take the same path to the same L2
+			 * channel (an address maps to one channel), which keeps them in order.  No other wave,
+			 * workgroup or agent writes this block's slot.  This is an argument about gfx9 hardware,
+			 * not a guarantee of the programming model; it is held by the soaks (tens of millions of
+			 * blocks, every one compared with the reference) and would show as wrong bytes there. */
 			{
 				const uint32_t total = rdlane(excl, nfit - 1) + rdlane(l, nfit - 1);
 				uint8_t *gbase = dst + op - sa; /* 16 B aligned */

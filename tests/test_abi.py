@@ -146,7 +146,8 @@ def test_gather_layout_and_the_c_gather_example():
     """csnappy_hip_gather_layout is host arithmetic; tools/gather_rccl_example.c -- the C sequence
     compact -> size exchange -> grouped ncclSend/ncclRecv that assembles the final stream of a
     block-sharded batch -- must compile against the product header and the image's HIP and RCCL
-    headers (it cannot run here: one GPU per box)."""
+    headers, warning-free, and the build must have linked it as a program (it runs in the -m gpu
+    suite: tests/test_gpu_parity.py::test_the_c_gather_example_runs_with_one_rank)."""
     import subprocess
     assert api.gather_layout([5, 0, 7, 1 << 40]) == ([0, 5, 5, 12], 12 + (1 << 40))
     assert api.gather_layout([]) == ([], 0)
@@ -154,3 +155,7 @@ def test_gather_layout_and_the_c_gather_example():
     r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I/opt/rocm/include", src],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    exe = os.path.join(ROOT, "tools", "gather_rccl_example")
+    assert os.path.exists(exe)
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libcsnappy.so" in needed and "librccl.so" in needed

@@ -747,6 +747,55 @@ def test_cl_tester_round_trip_and_selftests(torch, urls, golden_dir, tmp_path):
     assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)
 
 
+def test_the_reference_caller_itself_runs_on_the_product_library(torch, urls, golden_dir, tmp_path):
+    """The drop-in claim with the reference's OWN caller: oracle/_ref/cl_tester_ref is
+    /root/reference/cl_tester.c (:14-114 do_decompress / do_compress, :127-238 the -S self tests and
+    main) compiled where it lies against include/csnappy.h and linked with csnappy_amd/lib/libcsnappy.so
+    by oracle/Makefile's `ref_caller` recipe -- not a stand-in written here.  The reference's own
+    `make cl_test` (Makefile:21-29) on it: compress | decompress restores urls.10K, -S d, -S c."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "cl_tester_ref")
+    assert os.path.exists(exe), "oracle/_ref/cl_tester_ref is built by __graft_entry__.build() where /root/reference exists"
+    run = lambda a, data=b"": subprocess.run([exe] + a, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    c = run(["-c"], urls)
+    assert c.returncode == 0, c.stderr
+    # (the reference's cl_tester passes workmem power 16: the golden of the compiled reference at p=16)
+    assert len(c.stdout) == GOLD["urls_whole"]["16"]["size"] and sha(c.stdout) == GOLD["urls_whole"]["16"]["sha256"]
+    d = run(["-d", "-c"], c.stdout)
+    assert d.returncode == 0 and d.stdout == urls
+    # the shipped fixtures through the reference's decompress path
+    shipped = open(os.path.join(golden_dir, "urls.10K.snappy"), "rb").read()
+    assert run(["-d", "-c"], shipped).stdout == urls
+    bad = run(["-d", os.path.join(golden_dir, "baddata3.snappy"), str(tmp_path / "out")])
+    assert bad.returncode == 7 and b"returned -5" in bad.stderr
+    sd = run(["-S", "d"])
+    assert sd.returncode == 0, sd.stderr
+    sc = run(["-S", "c"])
+    assert sc.returncode == 0 and b"compression overwrites out buffer" in sc.stdout, (sc.returncode, sc.stdout, sc.stderr)
+
+
+def test_the_c_gather_example_runs_with_one_rank(torch, tmp_path):
+    """tools/gather_rccl_example.c as a program: a plain-C process compresses 48 blocks through the
+    C-ABI, then dense offsets -> compaction -> ncclAllGather of the byte counts -> layout -> the grouped
+    exchange on a communicator of one rank (all a 1-GPU box can run: ncclSend/ncclRecv between
+    ranks stay unmeasured on hardware).  Its stream == what shard.compact gives for the same batch."""
+    import subprocess
+    from csnappy_amd import shard
+    exe = os.path.join(os.path.dirname(HERE), "tools", "gather_rccl_example")
+    out = tmp_path / "stream.bin"
+    nblocks, block, seed = 48, 65536, 0xC5A90001
+    r = subprocess.run([exe, str(out), str(nblocks), hex(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    got = out.read_bytes()
+    d_in = api.generate(api.WG_TEXT, seed, 0, nblocks, block)
+    b = api.Batch([block] * nblocks)
+    d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
+    api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len, 16, api.STREAM, b.d_ws)
+    dense, _ = shard.compact(d_out, b.d_out_off, b.d_out_len)
+    torch.cuda.synchronize()
+    assert got == bytes(dense.cpu().numpy()) and b"from 1 rank" in r.stdout
+
+
 PLACEMENTS = ["hash", "dense", "global", "dense-cap256", "dense-cap1024-spill6144", "dense-nospill"]
 
 

@@ -13,14 +13,24 @@
  *      -- seven peers use seven different xGMI links into the root; nothing is staged or padded
  *
  * The library does not link RCCL; this file shows the calls a caller makes with ITS communicator.
- * It is compiled (not run: there is one GPU per test box) by tests/test_abi.py.
+ *
+ * It is also a program (main() below): one process, one GPU, one communicator of ONE rank -- all a
+ * 1-GPU test box can run.  It compresses NBLOCKS blocks of G_text, gathers "all ranks'" streams
+ * to the root and writes the assembled stream to the file named on the command line;
+ * tests/test_gpu_parity.py builds it (gcc, against include/csnappy_hip.h, libcsnappy.so and the
+ * librccl.so beside torch's HIP runtime), runs it and compares the file with the stream
+ * csnappy_amd/shard.py compacts from the same batch.  With one rank the ncclAllGather and the
+ * grouped (empty) exchange do run on the device; ncclSend/ncclRecv between ranks stay unmeasured
+ * until an 8-GPU node sees this (the gloo tests cover the layout logic).
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
+#include "../include/csnappy.h"
 #include "../include/csnappy_hip.h"
 
 #define MAX_RANKS 64
@@ -92,3 +102,64 @@ out:
 	(void)hipFree(d_all);
 	return rc;
 }
+
+#ifndef GATHER_EXAMPLE_NO_MAIN
+/* usage: gather_rccl_example OUT_FILE [nblocks [seed]]  -- see the header comment */
+#define CHECK(x)                                                                                    \
+	do {                                                                                        \
+		if (!(x)) {                                                                         \
+			fprintf(stderr, "%s:%d: %s failed (%s)\n", __FILE__, __LINE__, #x,           \
+				csnappy_hip_last_error());                                          \
+			return 1;                                                                   \
+		}                                                                                   \
+	} while (0)
+
+int main(int argc, char **argv)
+{
+	const uint32_t block = 65536, nblocks = argc > 2 ? (uint32_t)strtoul(argv[2], NULL, 0) : 48;
+	const uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 0) : 0xC5A90001ull;
+	const uint32_t slot = csnappy_max_compressed_length(block);
+	const size_t ws_bytes = csnappy_hip_compress_workspace_size(nblocks, block);
+	uint64_t *h_off = malloc((size_t)nblocks * 8 * 2), total = 0;
+	uint32_t *h_len = malloc((size_t)nblocks * 4), b;
+	void *d_in, *d_out, *d_ws, *d_in_off, *d_out_off, *d_in_len, *d_out_len, *d_stream = NULL;
+	hipStream_t stream;
+	ncclUniqueId id;
+	ncclComm_t comm;
+	char *h_stream;
+	FILE *f;
+
+	if (argc < 2 || !h_off || !h_len) {
+		fprintf(stderr, "usage: %s OUT_FILE [nblocks [seed]]\n", argv[0]);
+		return 2;
+	}
+	CHECK(csnappy_hip_device_count() > 0);
+	CHECK(hipSetDevice(0) == hipSuccess && hipStreamCreate(&stream) == hipSuccess);
+	/* the caller's communicator: here of one rank */
+	CHECK(ncclGetUniqueId(&id) == ncclSuccess && ncclCommInitRank(&comm, 1, id, 0) == ncclSuccess);
+	CHECK(hipMalloc(&d_in, (size_t)nblocks * block) == hipSuccess);
+	CHECK(hipMalloc(&d_out, (size_t)nblocks * slot) == hipSuccess && hipMalloc(&d_ws, ws_bytes) == hipSuccess);
+	CHECK(hipMalloc(&d_in_off, (size_t)nblocks * 8) == hipSuccess && hipMalloc(&d_out_off, (size_t)nblocks * 8) == hipSuccess);
+	CHECK(hipMalloc(&d_in_len, (size_t)nblocks * 4) == hipSuccess && hipMalloc(&d_out_len, (size_t)nblocks * 4) == hipSuccess);
+	for (b = 0; b < nblocks; b++) {
+		h_off[b] = (uint64_t)b * block;
+		h_off[nblocks + b] = (uint64_t)b * slot;
+		h_len[b] = block;
+	}
+	CHECK(hipMemcpy(d_in_off, h_off, (size_t)nblocks * 8, hipMemcpyHostToDevice) == hipSuccess);
+	CHECK(hipMemcpy(d_out_off, h_off + nblocks, (size_t)nblocks * 8, hipMemcpyHostToDevice) == hipSuccess);
+	CHECK(hipMemcpy(d_in_len, h_len, (size_t)nblocks * 4, hipMemcpyHostToDevice) == hipSuccess);
+	/* this rank's block range, compressed with no collective */
+	CHECK(csnappy_hip_workload_generate(0, seed, 0, nblocks, block, d_in, stream) == 0);
+	CHECK(csnappy_hip_compress_batch(d_in, d_in_off, d_in_len, nblocks, block, d_out, d_out_off, d_out_len, 16,
+					 CSNAPPY_HIP_STREAM, d_ws, ws_bytes, stream) == 0);
+	/* the one collective of the path */
+	CHECK(gather_final_stream(d_out, d_out_off, d_out_len, nblocks, 0, 1, 0, comm, stream, &d_stream, &total) == 0);
+	CHECK((h_stream = malloc(total ? total : 1)) != NULL);
+	CHECK(hipMemcpy(h_stream, d_stream, total, hipMemcpyDeviceToHost) == hipSuccess);
+	CHECK((f = fopen(argv[1], "wb")) != NULL && fwrite(h_stream, 1, total, f) == total && fclose(f) == 0);
+	printf("gathered %llu bytes of %u blocks from 1 rank\n", (unsigned long long)total, nblocks);
+	ncclCommDestroy(comm);
+	return 0;
+}
+#endif
