@@ -1130,6 +1130,15 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense
 		parse_lean<TAB_LDS_DENSE, false, true>(A, F);
 }
 
+/* debug: the global-table kernel with the same counters (G_low takes this kernel) */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_prof(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, true))
+		return;
+	parse_lean<TAB_GLOBAL, false, true>(A, F);
+}
+
 /* ==========================================================================================
  * COMPRESS, part 2 of 2: the emit launches (snappy_emit_sizes / _bases / _blocks; _pages)
  *
@@ -3403,13 +3412,13 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.p = p;
 	A.mode = mode;
 
-	/* (the s_memtime phase counters of tools/phase_lean.py exist for the dense placement only) */
+	/* (the s_memtime phase counters of tools/phase_lean.py exist for the dense and the global placement) */
+	const void *k2 = g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof)
+				    : reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
 	const void *k1 = P.tab == TAB_LDS_DENSE
 				 ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof)
 					       : reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean))
-			 : P.tab == TAB_LDS_HASH ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean)
-						 : reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
-	const void *k2 = reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
+			 : P.tab == TAB_LDS_HASH ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean) : k2;
 	if (!hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
 		    "hipFuncSetAttribute") ||
 	    (P.fallback &&
