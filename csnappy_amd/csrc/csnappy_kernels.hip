@@ -1837,14 +1837,6 @@ __device__ unsigned long long g_dec_prof[32];
 #endif
 [[maybe_unused]] constexpr int kWalkGroup = 4; /* tags per end-of-walk test where the plain walk is used */
 constexpr uint32_t kOutStage = 2048; /* bytes of a batch's output assembled in LDS */
-/* 1: the staging is a RING over the block's output (ring offset = address mod kOutStage), so what
- * earlier batches flushed is still there -- the last kOutStage bytes less what the current batch
- * overwrites -- and a copy whose source lies in it reads LDS, not HBM (csnappy_decompress.c:295-317
- * reads its own output through the cache; a wave here would otherwise fetch a 128-byte line for
- * nine bytes).  No second buffer, nothing is moved. */
-#ifndef CSNAPPY_DEC_RING
-#define CSNAPPY_DEC_RING 1
-#endif
 
 /* The reference's char_table (csnappy_decompress.c:152-185) as the kernels use it, computed by
  * the wave (4 entries per lane): bits 0-6 length (0 for a literal whose length follows in extra
@@ -1917,8 +1909,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 	__shared__ __attribute__((aligned(16))) uint8_t ostage[kOutStage + 16 + 64];
 	uint32_t qh = 0, qn = 0;
 	const uint64_t lt_mask = (1ull << lane) - 1;
-	[[maybe_unused]] uint32_t hbase = 0; /* ring: output bytes [max(hbase, op - kOutStage), op) are in the staging */
-	const uint32_t dst_lo = (uint32_t)reinterpret_cast<uintptr_t>(dst);
 	while (status == CSNAPPY_E_OK) {
 		/* ================= phase 1: scan -- find the real tags, queue what they decode to ======
 		 * Every lane decodes the byte at ip+lane as if it were a tag (one LDS load of the
@@ -2081,15 +2071,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 		 * whose output fits the staging; staged byte t is output byte op + t and sits at
 		 * ostage[sa + t], sa = (dst + op) & 15, so LDS 16 B chunks line up with global ones. */
 		const uint32_t nrun = fe < 64 ? fe : m;
-#if CSNAPPY_DEC_RING
-		/* ring offset of the batch's first byte; an element must START inside the ring, and one of
-		 * <= 64 bytes may run over its end into the 64 bytes of slack behind it (they are copied to
-		 * the ring's start after the flush), so the element behind it no longer fits this batch */
-		const uint32_t sa = (dst_lo + op) & (kOutStage - 1);
-		const uint64_t fitmask = ballot64(exec_me && sa + excl < kOutStage && sa + excl + l <= kOutStage + (l <= 64 ? 64u : 0u));
-#else
 		const uint64_t fitmask = ballot64(exec_me && excl + l <= kOutStage);
-#endif
 		const uint32_t nfit = ~fitmask ? first_lane(~fitmask) : 64u;
 		DEC_TICK(4); /* queue read, checks, offsets */
 		DEC_COUNT(2, nfit);
@@ -2123,7 +2105,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			if (body + lane < L)
 				pd[body + lane] = ps[body + lane];
 			op += L;
-			hbase = op; /* (these bytes did not pass through the ring) */
 			qh = (qh + 1) & 127u;
 			qn -= 1;
 			DEC_TICK(10); /* long literal, straight to HBM */
@@ -2131,9 +2112,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			continue;
 		}
 		if (nfit > 0) {
-#if !CSNAPPY_DEC_RING
 			const uint32_t sa = (uint32_t)(reinterpret_cast<uintptr_t>(dst + op) & 15u);
-#endif
 			const bool mine = lane < nfit;
 			uint8_t *o = ostage + sa + excl;
 			const bool lit = mine && is_lit;
@@ -2141,22 +2120,7 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			const bool indep = cpy && off >= excl + l; /* source ends in front of this batch's output */
 			/* ---- literals up to 64 bytes (SAW__Append / SAW__AppendFastPath, :264-293) and copies
 			 * that read only what earlier batches produced, one lane per element ---- */
-#if CSNAPPY_DEC_RING
-			/* a source in front of the batch that the ring still holds, and that does not run over
-			 * the ring's end, is read from LDS.  (All of copy_exact's loads are issued in front of its
-			 * stores, and LDS executes a wave's accesses in order: no lane's source is overwritten by
-			 * another lane's output before it was read.) */
-			const uint32_t sp = pb - off; /* (copies that passed the checks: off <= pb) */
-			const uint32_t hlo = max(hbase, op - min(op, kOutStage));
-			const uint32_t sr = (dst_lo + sp) & (kOutStage - 1);
-			const bool in_ring = indep && sp >= hlo && sr + l <= kOutStage;
-			const uint8_t *from = lit ? src + (at + hsz) : in_ring ? static_cast<const uint8_t *>(ostage + sr) : dst + sp;
-			copy_exact(o, from, l, (lit && l <= 64) || indep, next8);
-			DEC_COUNT(6, __builtin_popcountll(ballot64(in_ring)));
-			DEC_COUNT(7, __builtin_popcountll(ballot64(indep)));
-#else
 			copy_exact(o, lit ? src + (at + hsz) : dst + pb - off, l, (lit && l <= 64) || indep, next8);
-#endif
 			DEC_TICK(6); /* one-lane copies: round trip, piece stores */
 			DEC_COUNT(3, __builtin_popcountll(ballot64(cpy && !indep)));
 			DEC_COUNT(4, __builtin_popcountll(ballot64(lit && l > 64)));
@@ -2181,12 +2145,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			/* ---- the other copies, in order (SAW__AppendFromSelf, :295-317): source inside this
 			 * batch's output or overlapping itself, dst[j] = dst[j mod offset - offset]; bytes from
 			 * in front of the batch come from HBM, the rest from the staging ---- */
-#if CSNAPPY_DEC_RING
-			/* (by now the batch's own stores have replaced the ring's OLDEST bytes -- its output takes the
-			 * ring offsets of what was written kOutStage bytes ago: only what is younger is still there) */
-			const uint32_t btotal = rdlane(excl, nfit - 1) + rdlane(l, nfit - 1);
-			const uint32_t hlo_dep = max(hbase, op + btotal - min(op + btotal, kOutStage));
-#endif
 			for (uint64_t dep = ballot64(cpy && !indep); dep;) {
 				const uint32_t t = first_lane(dep);
 				asm("s_bitset0_b64 %0, %1" : "+s"(dep) : "s"(t));
@@ -2202,20 +2160,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 						j = min(r, r - OFF);
 					}
 					const int32_t s = (int32_t)(E + j) - (int32_t)OFF; /* relative to the batch's start */
-#if CSNAPPY_DEC_RING
-					/* in front of the batch: from the ring while it holds the byte (its offset wraps; the
-					 * batch's own bytes do not: they may lie in the slack behind the ring's end) */
-					const bool old = s < 0, held = old && op + s >= hlo_dep;
-					uint32_t byte = ostage[old ? (sa + (uint32_t)s) & (kOutStage - 1) : sa + (uint32_t)s];
-					asm volatile("" : "+v"(byte)); /* keeps the two loads apart (merged, they become one flat load) */
-					if (old && !held)
-						byte = dst[(int64_t)op + s];
-#else
 					uint32_t byte = ostage[sa + (uint32_t)max(s, 0)];
 					asm volatile("" : "+v"(byte)); /* keeps the two loads apart (merged, they become one flat load) */
 					if (s < 0)
 						byte = dst[(int64_t)op + s];
-#endif
 					ostage[sa + E + lane] = (uint8_t)byte;
 				}
 				wave_lds_fence();
@@ -2236,35 +2184,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 			 * blocks, every one compared with the reference) and would show as wrong bytes there. */
 			{
 				const uint32_t total = rdlane(excl, nfit - 1) + rdlane(l, nfit - 1);
-#if CSNAPPY_DEC_RING
-				/* ring chunk k (its bytes 16k .. 16k+15) is the 16-byte chunk of global memory at
-				 * gbase + 16k: the ring offset is the address modulo kOutStage, a multiple of 16 */
-				uint8_t *gbase = dst + op - sa;
-				const uint32_t end = sa + total; /* <= kOutStage + 64 */
-				const uint32_t c0 = sa >> 4, h0 = sa & 15u;
-				uint32_t first_full = c0;
-				if (h0 > 0) {
-					const uint32_t hend = min(16u * c0 + 16u, end);
-					if (16u * c0 + lane >= sa && 16u * c0 + lane < hend)
-						gbase[16u * c0 + lane] = ostage[16u * c0 + lane];
-					first_full = c0 + 1;
-				}
-				const uint32_t nfull = end >> 4;
-				for (uint32_t cc = first_full + lane; cc < nfull; cc += 64)
-					reinterpret_cast<uint4 *>(gbase)[cc] = reinterpret_cast<const uint4 *>(ostage)[cc];
-				const uint32_t tail0 = nfull << 4;
-				const uint32_t tail = (end > tail0 && (nfull > c0 || h0 == 0)) ? end - tail0 : 0;
-				if (lane < tail)
-					gbase[tail0 + lane] = ostage[tail0 + lane];
-				op += total;
-				wave_lds_fence();
-				if (end > kOutStage) {
-					/* the bytes in the slack are the ring's first bytes from now on */
-					if (lane < end - kOutStage)
-						ostage[lane] = ostage[kOutStage + lane];
-					wave_lds_fence();
-				}
-#else
 				uint8_t *gbase = dst + op - sa; /* 16 B aligned */
 				const uint32_t end = sa + total;
 				uint32_t first_full = 0;
@@ -2283,7 +2202,6 @@ extern "C" __global__ void __launch_bounds__(64) snappy_decompress_blocks(Decomp
 					gbase[tail0 + lane] = ostage[tail0 + lane];
 				op += total;
 				wave_lds_fence();
-#endif
 			}
 			DEC_TICK(9); /* flush */
 		}
