@@ -36,7 +36,7 @@ HIP_SYMBOLS = [
 
 FRAME_SYMBOLS = [
     "csnappy_frame_max_compressed_length", "csnappy_frame_compress", "csnappy_frame_uncompressed_length",
-    "csnappy_frame_decompress", "csnappy_hip_crc32c_batch",
+    "csnappy_frame_decompress", "csnappy_hip_crc32c_batch", "csnappy_frame_release",
 ]
 FRAME_E_NO_IDENTIFIER, FRAME_E_BAD_CHUNK, FRAME_E_CRC, FRAME_E_OUTPUT_INSUF, FRAME_E_DATA = -201, -202, -203, -204, -205
 

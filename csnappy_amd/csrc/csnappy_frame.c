@@ -48,23 +48,51 @@ enum { FB_IN, FB_OUT, FB_OFF, FB_LEN, FB_WS, FB_FRAMED, FB_COUNT };
 static struct {
 	void *p;
 	size_t cap;
+	int dev; /* the device the buffer lives on */
 } g_fb[FB_COUNT];
 static pthread_mutex_t g_fb_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* (g_fb_mu held) a buffer of >= bytes on the CALLING thread's current device: one that was grown by a
+ * thread with another device current is released and allocated anew here */
 static void *fb_get(int slot, size_t bytes)
 {
-	if (g_fb[slot].cap < bytes) {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return NULL;
+	if (g_fb[slot].cap < bytes || g_fb[slot].dev != dev) {
 		void *p = NULL;
-		if (g_fb[slot].p)
+		if (g_fb[slot].p) {
+			int back = dev;
+			(void)hipSetDevice(g_fb[slot].dev);
 			(void)hipFree(g_fb[slot].p);
+			(void)hipSetDevice(back);
+		}
 		g_fb[slot].p = NULL;
 		g_fb[slot].cap = 0;
 		if (hipMalloc(&p, bytes) != hipSuccess)
 			return NULL;
 		g_fb[slot].p = p;
 		g_fb[slot].cap = bytes;
+		g_fb[slot].dev = dev;
 	}
 	return g_fb[slot].p;
+}
+
+void csnappy_frame_release(void)
+{
+	int slot, back = 0;
+	pthread_mutex_lock(&g_fb_mu);
+	(void)hipGetDevice(&back);
+	for (slot = 0; slot < FB_COUNT; slot++) {
+		if (g_fb[slot].p) {
+			(void)hipSetDevice(g_fb[slot].dev);
+			(void)hipFree(g_fb[slot].p);
+		}
+		g_fb[slot].p = NULL;
+		g_fb[slot].cap = 0;
+	}
+	(void)hipSetDevice(back);
+	pthread_mutex_unlock(&g_fb_mu);
 }
 
 static uint32_t rd_le24(const unsigned char *p)

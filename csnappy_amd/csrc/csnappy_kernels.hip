@@ -1645,8 +1645,12 @@ extern "C" __global__ void __launch_bounds__(64) snappy_emit_bases(CompressArgs 
 	const uint32_t nfr = len ? (len + kFragment - 1) / kFragment : 1;
 	/* a fragment no parser launch finished (an internal error, never seen: the parsers give up
 	 * instead of spinning when their cursor stops moving): the block is reported as failed */
-	for (uint32_t fi = 0; fi < nfr; ++fi) {
-		if (A.rec_cnt[blockIdx.x * A.fpb + fi] >= kWantGlobal) {
+	/* (64 fragments per load: one long stream has 32 768 of them per GiB, and a serial loop here was
+	 * the one-wave tail the three-launch emit exists to avoid) */
+	for (uint32_t f0 = 0; f0 < nfr; f0 += 64) {
+		const uint32_t fi = f0 + lane;
+		const bool unparsed = fi < nfr && A.rec_cnt[blockIdx.x * A.fpb + fi] >= kWantGlobal;
+		if (ballot64(unparsed)) {
 			if (lane == 0)
 				A.out_len[blk] = 0xffffffffu;
 			return;
@@ -2999,6 +3003,12 @@ struct Timer {
 	{
 		if (!on)
 			return;
+		/* (a stop() that found the pending list full left its pair here) */
+		if (a)
+			(void)hipEventDestroy(a);
+		if (b)
+			(void)hipEventDestroy(b);
+		a = b = nullptr;
 		(void)hipEventCreate(&a);
 		(void)hipEventCreate(&b);
 		(void)hipEventRecord(a, st);

@@ -54,6 +54,14 @@ size_t csnappy_frame_max_compressed_length(size_t n);
  */
 int csnappy_frame_compress(const char *src, size_t n, char *dst, size_t *dst_len, int p);
 
+/*
+ * csnappy_frame_compress keeps its device buffers between calls (input, slot-strided and framed
+ * output, descriptors, the codec's workspace: about 3.3 x the largest n seen plus up to 4.1 GiB of
+ * workspace), on the device that was current when they were grown; a call made with another device
+ * current moves them there.  This returns them to the runtime.  Calls are serialised internally.
+ */
+void csnappy_frame_release(void);
+
 /* Walks the chunks (no device work): total uncompressed size of a well-formed stream. */
 int csnappy_frame_uncompressed_length(const char *src, size_t n, size_t *result);
 
