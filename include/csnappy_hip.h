@@ -90,7 +90,9 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
  * as csnappy_decompress_noheader(d_in, in_len, d_out, &ulength) (csnappy_decompress.c:319-387):
  * `ulength` is *dst_len on entry (the room in d_out), d_status[0] receives the reference's return
  * code, d_produced[0] the bytes produced (status 0: *dst_len on exit, possibly less than ulength;
- * -3 / -5: the length of the decoded prefix in d_out).  csnappy_decompress (:390-415) is this call after the length header has been parsed
+ * -3 / -5: the length of the decoded prefix in d_out -- the bytes of d_out between `produced` and
+ * `ulength` are UNSPECIFIED after an error: the parallel fragment pass has written there before the
+ * one-wave decode re-did the prefix; with status 0 nothing beyond `produced` is written).  csnappy_decompress (:390-415) is this call after the length header has been parsed
  * (the header's value is `ulength`).
  *
  * A pre-pass indexes the tags of the body with one wave per 4 KiB and looks for the elements that

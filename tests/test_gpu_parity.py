@@ -389,6 +389,9 @@ def _stream_call(torch, stream, chk):
     st, produced, fast = api.decompress_stream(body, ulen, d_out)
     out = d_out.cpu().numpy()
     assert (out[ulen:] == 0xA5).all(), "wrote past the expected length"
+    # status 0: the bytes produced; -3 / -5: the decoded prefix, which `produced` measures (the bytes of
+    # d_out between it and ulength are unspecified then: the parallel fragment pass wrote there first)
+    _stream_call.prefix = bytes(out[:produced]) if st in (-3, -5) else b""
     return st, bytes(out[:produced]) if st == 0 else b"", fast
 
 
@@ -578,13 +581,19 @@ def test_damaged_long_streams_report_what_the_reference_reports(torch, chk, urls
     cases.append(bytes(good) + b"\x00")           # one more (1-byte literal) element than the length allows
     cases.append(bytes(good) + bytes(200000))      # ... and many more
     from test_oracle import _body_has_truncated_tag
-    fasts = 0
+    fasts = nprefix = 0
     for s in cases:
         if _body_has_truncated_tag(s, hdr):
             continue  # the reference reads past the input there: undefined
         rc, ref = chk.decompress(s, len(data))
         st, out, fast = _stream_call(torch, s, chk)
         assert st == rc, (st, rc)
+        if rc in (-3, -5):
+            # the reference's writer stores as it goes (csnappy_decompress.c:258-317): what it left in dst
+            # in front of the failing element is what the stream call leaves and measures
+            pre = _stream_call.prefix
+            assert pre == ref[:len(pre)]
+            nprefix += len(pre) > 0
         if rc == 0:
             assert out == ref[:len(out)] and len(out) <= len(data)
             # a stream that decodes cleanly but produces less than its header says is CSNAPPY_E_OK
@@ -592,6 +601,7 @@ def test_damaged_long_streams_report_what_the_reference_reports(torch, chk, urls
             assert chk.decompress_noheader(s[hdr:], len(data))[1] == len(out)
         fasts += fast
     assert 0 < fasts < len(cases)
+    assert nprefix >= 5, "most damaged streams fail behind a decoded prefix"
 
 
 def test_stream_call_on_short_and_empty_bodies(torch, chk):
@@ -1103,6 +1113,13 @@ def test_framing_writer_and_reader_against_the_spec_restatement(torch, urls, p):
             g = got[:10] + b"\xfe\x05\x00\x00hello" + got[10:cut] + b"\x99\x00\x00\x00" + got[:10] + got[cut:] + b"\xfe\x00\x00\x00"
             assert frame.decode(g, dec, ulen) == (0, x)
             assert api.frame_decompress(g, len(x) + 5) == (0, x)
+    # the writer keeps its device buffers between calls; giving them back leaves it usable
+    L = api.lib()
+    L.csnappy_frame_release.restype = None
+    L.csnappy_frame_release()
+    L.csnappy_frame_release()
+    rc, got = api.frame_compress(urls[:200000], p)
+    assert rc == 0 and got == frame.encode(urls[:200000], lambda c: comp(c, p))
 
 
 def test_framing_reader_rejects_what_the_spec_rejects(torch, urls):
