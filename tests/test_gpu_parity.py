@@ -994,6 +994,50 @@ def test_legacy_api_large_single_stream_and_threads(torch, chk):
     assert got == want
 
 
+def test_batch_calls_from_four_threads_on_their_own_streams(torch, chk):
+    """include/csnappy_hip.h: the batch calls keep no state between calls and may be issued from
+    several threads, each with its own buffers, workspace and stream.  Four threads, four streams,
+    different workloads and table powers at once; every block equals the checker's and round-trips."""
+    import threading
+    jobs = [(api.WG_TEXT, 16, api.STREAM, 65536, 96), (api.WG_LOW, 16, api.STREAM, 65536, 96),
+            (api.WG_PAGE, 13, api.FRAGMENT, 4096, 1024), (api.WG_TEXT, 15, api.STREAM, 40000, 128)]
+    errs, results = [], [None] * 4
+
+    def work(i):
+        try:
+            kind, p, mode, block, nb = jobs[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                host = api.generate_host(kind, 7000 + i, 0, nb, block)
+                d_in = torch.from_numpy(host.copy()).cuda()
+                b = api.Batch([block] * nb)
+                d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
+                d_back = torch.zeros(nb * block, dtype=torch.uint8, device="cuda")
+                cap = torch.full((nb,), block, dtype=torch.int32, device="cuda")
+                status = torch.full((nb,), -99, dtype=torch.int32, device="cuda")
+                produced = torch.zeros(nb, dtype=torch.int32, device="cuda")
+                for _ in range(6):
+                    api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len,
+                                       p, mode, b.d_ws)
+                    api.decompress_batch(d_out, b.d_out_off, b.d_out_len, d_back, b.d_in_off, cap, status, produced, mode)
+                st.synchronize()
+                assert (status == 0).all().item() and torch.equal(d_back, d_in)
+                results[i] = (host, d_out.cpu().numpy(), b.d_out_len.cpu().numpy(), b.out_off)
+        except Exception as e:  # noqa
+            errs.append((i, repr(e)))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    # (the checker keeps one working memory per instance: it is consulted from this thread only)
+    for i, (kind, p, mode, block, nb) in enumerate(jobs):
+        host, got, lens, out_off = results[i]
+        want = chk.compress_blocks(host, block, p, mode)
+        for k in range(nb):
+            o = int(out_off[k])
+            assert bytes(got[o:o + int(lens[k])]) == want[k], (i, k)
+
+
 def test_rccl_gather_of_the_compacted_stream_single_rank(torch, urls):
     """The only collective of the path (assembling the final stream) over RCCL with one rank: the
     gathered bytes equal the concatenation of the per-block outputs."""
