@@ -193,7 +193,10 @@ class GpuEngine:
         return rep[idx]
 
     def batch(self, lens):
-        return self.api.Batch(lens)
+        # HBM is 288 GB: the workspace is sized for parser launches of up to 8 GiB of input (a 1 GiB
+        # batch is one launch either way: 4.1 GiB of workspace; an 8 GiB chunk of the large
+        # configurations is one launch instead of eight, whose ramps and tails cost 5-11 %: 33 GiB)
+        return self.api.Batch(lens, launch_gib=8)
 
     def zeros(self, n, dtype):
         return self.torch.zeros(n, dtype=dtype, device="cuda")

@@ -27,6 +27,7 @@ LEGACY_SYMBOLS = [
 ]
 HIP_SYMBOLS = [
     "csnappy_hip_device_count", "csnappy_hip_last_error", "csnappy_hip_compress_workspace_size",
+    "csnappy_hip_compress_workspace_size_for",
     "csnappy_hip_compress_batch", "csnappy_hip_decompress_batch", "csnappy_hip_set_kernel_timing",
     "csnappy_hip_get_kernel_timing", "csnappy_hip_workload_generate", "csnappy_hip_compact_batch",
     "csnappy_workload_generate_host", "csnappy_hip_decompress_stream_workspace_size",
@@ -78,6 +79,8 @@ def lib():
     L.csnappy_hip_last_error.restype = C.c_char_p
     L.csnappy_hip_compress_workspace_size.restype = C.c_size_t
     L.csnappy_hip_compress_workspace_size.argtypes = [u32, u32]
+    L.csnappy_hip_compress_workspace_size_for.restype = C.c_size_t
+    L.csnappy_hip_compress_workspace_size_for.argtypes = [u32, u32, u32]
     L.csnappy_hip_compress_batch.restype = i32
     L.csnappy_hip_compress_batch.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, i32, i32, vp,
                                              C.c_size_t, vp]
@@ -239,8 +242,9 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def workspace_size(nblocks, max_in_len):
-    return lib().csnappy_hip_compress_workspace_size(nblocks, max_in_len)
+def workspace_size(nblocks, max_in_len, launch_gib=1):
+    """Scratch for launches of up to launch_gib GiB of input (1: the least the batch call accepts)."""
+    return lib().csnappy_hip_compress_workspace_size_for(nblocks, max_in_len, launch_gib)
 
 
 def compress_batch(d_in, in_off, in_len, max_in_len, d_out, out_off, out_len, p, mode, workspace):
@@ -347,7 +351,9 @@ class Batch:
     input, each with an output slot of csnappy_max_compressed_length(len) bytes rounded up to
     `slot_align`."""
 
-    def __init__(self, lens, slot_align=64, device="cuda"):
+    def __init__(self, lens, slot_align=64, device="cuda", launch_gib=1):
+        """launch_gib: size the workspace for parser launches of up to this many GiB of input (1 is
+        the least the batch call accepts; larger launches lose less to their ramp and tail)."""
         import torch
         lens = np.asarray(lens, dtype=np.uint32)
         self.n = len(lens)
@@ -368,11 +374,11 @@ class Batch:
             self.d_in_len = t(self.in_len, np.int32)
             self.d_out_off = t(self.out_off, np.int64)
             self.d_out_len = torch.zeros(self.n, dtype=torch.int32, device=device)
-            self.d_ws = torch.empty(workspace_size(self.n, self.max_in_len) + 256, dtype=torch.uint8,
-                                    device=device)
+            need = workspace_size(self.n, self.max_in_len, launch_gib)
+            self.d_ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
             # 256-byte aligned view
             off = (-self.d_ws.data_ptr()) % 256
-            self.d_ws = self.d_ws[off:off + workspace_size(self.n, self.max_in_len)]
+            self.d_ws = self.d_ws[off:off + need]
 
     @classmethod
     def uniform(cls, total_bytes, block_len, **kw):

@@ -3027,7 +3027,9 @@ struct Timer {
 };
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
-constexpr uint32_t kChunkFragments = 32768; /* fragments parsed per launch (bounds the workspace) */
+constexpr uint32_t kChunkFragments = 32768; /* full fragments per GiB of a launch (the unit the workspace is sized in) */
+constexpr uint32_t kChunkFragmentsMax = 262144; /* short fragments (pages): as many as make up the same input, at most this per GiB */
+constexpr uint32_t kLaunchGibMax = 8;
 /* entries of the dense LDS table: 9 KiB + 1 KiB of filters = eight of gfx950's 1 280-byte LDS
  * granules, 16 fragments per CU (5 120 entries need nine: 14 per CU).  Fragments with more buckets
  * -- a quarter of G_text's, by a few dozen; most of urls.10K's, by a few hundred -- keep the rest
@@ -3267,17 +3269,26 @@ struct Workspace {
 	uint32_t chunk_blocks, chunk_frags, rec_cap, tab_stride;
 };
 
-Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn)
+/* launch_gib: GiB of input one parser launch covers (1..kLaunchGibMax) */
+Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn, uint32_t launch_gib = 1)
 {
 	Workspace W;
 	const uint32_t fpb = frags_per_block(max_in_len);
-	uint32_t cb = kChunkFragments / fpb;
+	/* a launch covers launch_gib GiB of input whatever the fragment size: a launch of 32 768 pages
+	 * (128 MiB) is 0.5 ms long and a tenth of that is its ramp and tail, and the ramp and tail of a
+	 * 1 GiB launch of full fragments are 5 % (text) to 11 % (runs) of it */
+	const uint32_t mf = max_fragment(max_in_len) ? max_fragment(max_in_len) : 1;
+	uint64_t cf = (uint64_t)kChunkFragments * kFragment / mf;
+	if (cf > kChunkFragmentsMax)
+		cf = kChunkFragmentsMax;
+	cf *= launch_gib;
+	uint64_t cb = cf / fpb;
 	if (cb < 1)
 		cb = 1;
 	if (cb > nblocks)
 		cb = nblocks;
-	W.chunk_blocks = cb;
-	W.chunk_frags = cb * fpb;
+	W.chunk_blocks = (uint32_t)cb;
+	W.chunk_frags = (uint32_t)cb * fpb;
 	W.rec_cap = record_cap(max_fragment(max_in_len));
 	W.tab_stride = tab_stride_for(max_fragment(max_in_len), kn);
 	W.cnt_bytes = ((uint64_t)W.chunk_frags * 4 + 255) & ~255ull;
@@ -3367,9 +3378,18 @@ void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4])
 
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len)
 {
+	return csnappy_hip_compress_workspace_size_for(nblocks, max_in_len, 1);
+}
+
+size_t csnappy_hip_compress_workspace_size_for(uint32_t nblocks, uint32_t max_in_len, uint32_t launch_gib)
+{
 	if (nblocks == 0)
 		return 65536;
-	return (size_t)plan_workspace(nblocks, max_in_len, knobs()).total;
+	if (launch_gib < 1)
+		launch_gib = 1;
+	if (launch_gib > kLaunchGibMax)
+		launch_gib = kLaunchGibMax;
+	return (size_t)plan_workspace(nblocks, max_in_len, knobs(), launch_gib).total;
 }
 
 int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
@@ -3386,9 +3406,18 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return CSNAPPY_HIP_E_ARG;
 	if (nblocks == 0)
 		return 0;
-	const Workspace W = plan_workspace(nblocks, max_in_len, kn);
+	/* the largest launches the caller's workspace has room for (csnappy_hip_compress_workspace_size_for);
+	 * csnappy_hip_compress_workspace_size() -- launches of 1 GiB -- is the least that is accepted */
+	Workspace W = plan_workspace(nblocks, max_in_len, kn, 1);
 	if (workspace_bytes < W.total || (reinterpret_cast<uintptr_t>(d_workspace) & 255))
 		return CSNAPPY_HIP_E_WORKSPACE;
+	for (uint32_t g = kLaunchGibMax; g > 1; --g) {
+		const Workspace Wg = plan_workspace(nblocks, max_in_len, kn, g);
+		if (Wg.total <= workspace_bytes) {
+			W = Wg;
+			break;
+		}
+	}
 	const uint32_t fpb = frags_per_block(max_in_len);
 	if ((uint64_t)nblocks * fpb > 0x7fffffffull)
 		return CSNAPPY_HIP_E_ARG;

@@ -994,6 +994,37 @@ def test_legacy_api_large_single_stream_and_threads(torch, chk):
     assert got == want
 
 
+def test_launch_size_follows_the_workspace_and_does_not_change_the_bytes(torch, chk):
+    """A batch of more than 1 GiB runs as several parser launches; how large they are follows from the
+    workspace the caller passes (csnappy_hip_compress_workspace_size: launches of 1 GiB, the least
+    accepted; ..._size_for(.., 4): launches of up to 4 GiB).  2 GiB + 5 blocks of G_low both ways:
+    three launches or one, the same bytes -- and the reference's around the launch boundaries."""
+    import hashlib
+    block, nb = 65536, 2 * 16384 + 5
+    d_in = api.generate(api.WG_LOW, 0xC5A90005, 0, nb, block)
+    small, large = api.Batch([block] * nb), api.Batch([block] * nb, launch_gib=4)
+    assert large.d_ws.numel() > 2 * small.d_ws.numel()
+    assert small.d_ws.numel() == api.workspace_size(1 << 22, block)  # the 1 GiB size is where it stops growing
+    d_out = torch.zeros(small.out_bytes, dtype=torch.uint8, device="cuda")
+    res = []
+    for b in (small, large):
+        d_out.zero_()
+        api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len, 16, api.STREAM, b.d_ws)
+        torch.cuda.synchronize()
+        lens = b.d_out_len.cpu().numpy().copy()
+        dense, _ = __import__("csnappy_amd.shard", fromlist=["compact"]).compact(d_out, b.d_out_off, b.d_out_len)
+        res.append((lens, hashlib.sha256(dense.cpu().numpy().tobytes()).hexdigest()))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    # the blocks on both sides of the 1 GiB launch boundaries against the checker
+    got = d_out.cpu().numpy()
+    host = api.generate_host(api.WG_LOW, 0xC5A90005, 0, nb, block)
+    for k in (0, 16383, 16384, 32767, 32768, nb - 1):
+        want = chk.compress(host[k * block:(k + 1) * block], 16)
+        o = int(small.out_off[k])
+        assert bytes(got[o:o + int(res[1][0][k])]) == want, k
+    del small, large
+
+
 def test_batch_calls_from_four_threads_on_their_own_streams(torch, chk):
     """include/csnappy_hip.h: the batch calls keep no state between calls and may be issued from
     several threads, each with its own buffers, workspace and stream.  Four threads, four streams,
