@@ -115,7 +115,7 @@ def test_batch_api_rejects_bad_arguments_before_touching_the_device():
     # workspace: 8-byte records (one per 4 input bytes at most) + 2-byte bucket ids per fragment
     assert L.csnappy_hip_compress_workspace_size(16384, 65536) >= 32768 * (8200 * 8 + 65536)
     assert L.csnappy_hip_compress_workspace_size(16384, 4096) < L.csnappy_hip_compress_workspace_size(16384, 65536)
-    # a batch is parsed in chunks of 32768 fragments: the workspace stops growing there
+    # a batch is parsed in launches of 1 GiB of input (32768 full fragments): the least workspace stops growing there
     assert L.csnappy_hip_compress_workspace_size(1 << 20, 65536) == L.csnappy_hip_compress_workspace_size(16384, 65536)
 
 
