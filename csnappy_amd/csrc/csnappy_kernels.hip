@@ -283,6 +283,9 @@ constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output s
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
 constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
+constexpr uint32_t kSpillFilterEntries = 128; /* the spilled lanes' conflict filter (u32 tags) ... */
+constexpr uint32_t kSpillFilterSlots = kSpillFilterEntries * 2; /* ... takes the place of this many table entries */
+constexpr uint32_t kLatePos = 0x7fc1;   /* table entries of positions from here on are within 63 of 0xffff (parse_lean, TW) */
 
 enum { TAB_LDS_HASH = 0, TAB_LDS_DENSE = 1, TAB_GLOBAL = 2 };
 
@@ -514,7 +517,9 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	}
 	uint32_t nb;
 	uint32_t run = wave_excl_scan(mine, lane, &nb);
-	if (nb > A.dense_cap + A.spill_cap) {
+	/* (a fragment with more buckets than the LDS table gives the table's last kSpillFilterSlots
+	 * entries to its spilled lanes' filter, see parse_lean) */
+	if (nb > A.dense_cap && nb > A.dense_cap + A.spill_cap - (A.spill_cap ? kSpillFilterSlots : 0u)) {
 		if (lane == 0)
 			A.rec_cnt[F.c] = kNoRecords;
 		return kNoRecords;
@@ -585,6 +590,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	const uint8_t *src = F.src;
 	uint2 *R = F.R;
 	uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+	uint32_t *tab32 = reinterpret_cast<uint32_t *>(smem);
 	/* TAB_GLOBAL: the full 2^p-byte table lies in the fragment's workspace region; LDS holds one bit per
 	 * slot, "written in this fragment".  A clear bit means the slot is empty (the reference's zeroed
 	 * table: candidate position 0) without touching memory, so the global table is never cleared and
@@ -593,11 +599,32 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	uint32_t *occ = reinterpret_cast<uint32_t *>(smem);
 	const uint16_t *ids = reinterpret_cast<const uint16_t *>(F.region);
 	uint16_t *spill = reinterpret_cast<uint16_t *>(F.region + A.spill_off);
-	uint32_t *S = reinterpret_cast<uint32_t *>(smem + A.lds0);
-	uint32_t *S2 = S + A.s_entries;
-	const uint32_t smask = A.s_entries - 1;
-	const uint32_t s_shift = A.s_shift, dense_cap = A.dense_cap;
-	const bool two_filters = DENSE || s_shift != 0;
+	/* TW (round 5): tables in LDS find the lanes of a step that share a slot through the table itself.
+	 * gfx950's LDS serves the lanes of one instruction that hit one address in ascending lane order
+	 * (tools/ubench/lds_order.hip; csnappy_hip_compress_batch checks it on the device before the first
+	 * launch): every lane reads its entry, then adds 1 to its 16-bit half of the entry's dword with a
+	 * RETURNING add -- what comes back is the entry plus the number of LOWER lanes with the same slot, so
+	 * "differs from the entry" is exactly "flagged".  The commit puts the entries back (one store) and
+	 * writes the inserted lanes' (a second store: of several lanes with one slot the highest survives,
+	 * which is the reference's order of updates).  The two conflict filters (two atomics, two reads,
+	 * thirty instructions of tag arithmetic per step, false alarms, 1 KiB of LDS) and the commit's
+	 * dedupe rounds are gone from those placements; the few lanes of a SPILL fragment whose bucket lives
+	 * in HBM keep one small filter among themselves, carved out of the table's tail.  The global table
+	 * keeps both filters (a returning atomic through memory would cost a round trip).
+	 * The add must not carry from the low half of a dword into the high one: entries are position |
+	 * check bit << 15 with positions < 32 754, at most 63 lower lanes -- a carry needs an entry of a
+	 * position >= kLatePos, and the steps that can see one flag every lane instead (the last one or
+	 * two of a full fragment; a flagged lane's visit is exact whatever flagged it). */
+	constexpr bool TW = !GTAB;
+	constexpr bool FILT = GTAB || SPILL;
+	/* TW + SPILL: the last kSpillFilterSlots entries of the LDS table are the spilled lanes' filter */
+	const uint32_t dense_cap = (TW && SPILL) ? A.dense_cap - kSpillFilterSlots : A.dense_cap;
+	uint32_t *S = reinterpret_cast<uint32_t *>(smem + (TW ? 2 * dense_cap : A.lds0));
+	const uint32_t s_entries = TW ? kSpillFilterEntries : A.s_entries;
+	uint32_t *S2 = S + s_entries;
+	const uint32_t smask = s_entries - 1;
+	const uint32_t s_shift = TW ? 0u : A.s_shift;
+	const bool two_filters = !TW && s_shift != 0;
 
 	uint32_t nev = 0;       /* records written */
 	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
@@ -610,9 +637,11 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint4 *z4 = reinterpret_cast<uint4 *>(smem);
 		for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
 			z4[k] = make_uint4(0, 0, 0, 0);
-		uint4 *s4 = reinterpret_cast<uint4 *>(S);
-		for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * A.s_entries) >> 2); k += 64)
-			s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+		if (FILT) {
+			uint4 *s4 = reinterpret_cast<uint4 *>(S);
+			for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
+				s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+		}
 		wave_lds_fence();
 	}
 
@@ -716,31 +745,43 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			const uint32_t slot = DENSE ? sid : prod >> shift;
 			const bool tabbed = DENSE ? valid_c && slot != kNoBucket : valid_c;
 			const uint32_t chk = (prod >> (shift - 1)) & 1u;
-			const uint32_t key = slot & smask;
-			const uint32_t key2 = DENSE ? ((slot >> s_shift) ^ (slot << (s_shift - 5))) & smask
-						    : (slot >> s_shift) & smask;
-			/* slot sharing inside a step: two small filters; see filter_tag() */
-			atomicMin(&S[key], FT::tag(epoch, slot, lane, tabbed));
-			if (two_filters)
-				atomicMin(&S2[key2], FT::tag(epoch, FT::kSlots - slot, lane, tabbed));
-			uint32_t cand;
+			const uint32_t mine16 = pos_c | (chk << 15); /* my table entry, if I am inserted */
 			const bool spilled = SPILL && tabbed && slot >= dense_cap;
-			if (GTAB) {
+			const bool in_lds = !GTAB && tabbed && !spilled;
+			uint32_t cand, raw16 = 0;
+			uint64_t cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
+			uint32_t bumped = 0;
+			/* TW: this step may see an entry that an add could carry out of (see above) */
+			const bool late = TW && (sparse_c ? scan_pos(s, q1 + 62) : s + q1 + 61) >= kLatePos;
+			uint32_t key = 0, key2 = 0;
+			if (!TW) {
+				key = slot & smask;
+				key2 = (slot >> s_shift) & smask;
+				/* slot sharing inside a step: two small filters; see FilterTag */
+				atomicMin(&S[key], FT::tag(epoch, slot, lane, tabbed));
+				if (two_filters)
+					atomicMin(&S2[key2], FT::tag(epoch, FT::kSlots - slot, lane, tabbed));
 				const bool written = tabbed && ((occ[slot >> 5] >> (slot & 31)) & 1u);
 				cand = gtab[written ? slot : 0u];
 				cand = written ? cand : 0u;
 			} else {
-				const bool in_lds = tabbed && !spilled;
-				cand = tab[in_lds ? slot : 0u];
-				cand = in_lds ? cand : 0u;
+				raw16 = tab[in_lds ? slot : 0u];
+				raw16 = in_lds ? raw16 : 0u;
+				if (in_lds && !late)
+					bumped = atomicAdd(&tab32[slot >> 1], 1u << ((slot & 1u) << 4));
+				cand = raw16;
 			}
 			if (SPILL && ballot64(spilled)) {
+				/* the lanes whose bucket lies in HBM: one filter among themselves (a lane it does not
+				 * settle is flagged to be safe; they are few, so that is rare) */
+				key = (slot - dense_cap) & smask;
+				atomicMin(&S[key], FT::tag(epoch, slot, lane, spilled));
 				const uint32_t g = spill[spilled ? slot - dense_cap : 0u];
 				cand = spilled ? g : cand;
 			}
 			wave_lds_fence();
 			/* the candidate's 16 bytes are requested as soon as the table entry is there, in front of
-			 * the filters' read-back (dense steps; lanes without a candidate read position 0 -- one
+			 * the read-back (dense steps; lanes without a candidate read position 0 -- one
 			 * broadcast line; masking them off the load, here and in the spill-over gather, changes
 			 * nothing: measured in round 3) */
 			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
@@ -752,15 +793,24 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				CSNAPPY_FLUSH_PREC();
 #endif
 			}
-			const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
-			const bool flagged = tabbed & FT::flags(fe1, fe2, slot, lane);
-			const uint64_t cmask = ballot64(flagged);
 			const uint64_t tmask = ballot64(tabbed);
-			if (--epoch == 0) {
+			if (!TW) {
+				const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
+				cmask = ballot64(tabbed & FT::flags(fe1, fe2, slot, lane));
+			} else {
+				/* my half of the dword as the add found it: the entry + the lower lanes of my slot */
+				const uint32_t seen = (bumped >> ((slot & 1u) << 4)) & 0xffffu;
+				cmask = late ? tmask & ~1ull : ballot64(in_lds && seen != raw16);
+				if (SPILL && ballot64(spilled)) {
+					const uint32_t fe1 = S[key];
+					cmask |= ballot64(spilled & FT::flags(fe1, ~0u, slot, lane));
+				}
+			}
+			if (FILT && --epoch == 0) {
 				/* the tags' epoch field is about to wrap: start over with empty filters */
 				wave_lds_fence();
 				uint4 *s4 = reinterpret_cast<uint4 *>(S);
-				for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * A.s_entries) >> 2); k += 64)
+				for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
 					s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 				wave_lds_fence();
 				epoch = FT::kEpochs;
@@ -1018,6 +1068,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				/* of several committed lanes with one slot only the last may write */
 				const uint64_t cm = ballot64(commit);
 				uint64_t fl = cmask & cm;
+				if (TW) /* (the LDS keeps the highest lane of a slot by itself; only stores to HBM need this) */
+					fl = SPILL ? fl & ballot64(spilled) : 0;
 				if (fl) {
 					/* one round per SLOT that several committed lanes share, highest lane first: it
 					 * keeps its write, the lower ones of its slot lose theirs (runs put one slot on
@@ -1035,14 +1087,22 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			}
 			if (GTAB) {
 				if (commit) {
-					gtab[slot] = (uint16_t)(pos_c | (chk << 15));
+					gtab[slot] = (uint16_t)mine16;
 					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
 				}
-			} else if (commit && !spilled) {
-				tab[slot] = (uint16_t)(pos_c | (chk << 15));
+			} else {
+				/* TW: the lanes that are not inserted put their entry back (the add changed it); then the
+				 * inserted ones write theirs -- a store of its own, so that it comes after every
+				 * restore of the same slot, and of several inserted lanes with one slot the LDS keeps
+				 * the highest (ascending lane order) */
+				if (in_lds && !commit)
+					tab[slot] = (uint16_t)raw16;
+				wave_lds_fence();
+				if (in_lds && commit)
+					tab[slot] = (uint16_t)mine16;
 			}
 			if (!CSNAPPY_PARSE_NOSPILLSTORE && SPILL && commit && spilled) /* (macro: timing experiment only) */
-				spill[slot - dense_cap] = (uint16_t)(pos_c | (chk << 15));
+				spill[slot - dense_cap] = (uint16_t)mine16;
 			wave_lds_fence();
 		}
 #if CSNAPPY_PARSE_NOSTORE == 4
@@ -2950,6 +3010,49 @@ extern "C" __global__ void __launch_bounds__(64) snappy_crc32c_blocks(CrcArgs A)
 }
 
 /* ==========================================================================================
+ * The LDS property the parsers with their table in LDS rely on (parse_lean, "TW"): the lanes of ONE
+ * LDS instruction that hit one address are served in ascending lane order -- a returning add hands
+ * every lane the sum of the LOWER lanes' addends, and of several stores the highest lane's data
+ * stays.  The ISA manual does not promise it; tools/ubench/lds_order.hip measured it on gfx950
+ * (2.5 M lanes in shared slots, no exception), and this probe repeats the measurement on the device
+ * in hand before the first parser launch of a process: a device that answers differently makes
+ * every compress call fail instead of producing a stream that is not the reference's.
+ * ======================================================================================== */
+extern "C" __global__ void __launch_bounds__(64) snappy_lds_order_probe(uint32_t *bad)
+{
+	__shared__ uint32_t cnt[64];
+	__shared__ uint16_t win[128];
+	const uint32_t lane = threadIdx.x;
+	uint32_t x = (blockIdx.x * 64 + lane) * 0x9E3779B9u + 0x7f4a7c15u, wrong = 0;
+	for (uint32_t round = 0; round < 32; ++round) {
+		cnt[lane] = 0;
+		win[lane] = 0xffff;
+		win[64 + lane] = 0xffff;
+		wave_lds_fence();
+		x ^= x << 13;
+		x ^= x >> 17;
+		x ^= x << 5;
+		/* few slots (runs put one slot on most lanes) up to many (text: a pair now and then) */
+		const uint32_t range = 1u + ((blockIdx.x + round) % 7u) * ((blockIdx.x + round) % 7u) * 2u;
+		const uint32_t slot = ((x >> 8) * range) >> 24; /* < range <= 73 */
+		const uint32_t got = atomicAdd(&cnt[slot >> 1], 1u << ((slot & 1u) << 4));
+		win[slot] = (uint16_t)lane;
+		wave_lds_fence();
+		uint32_t lower = 0, highest = lane;
+		for (uint32_t j = 0; j < 64; ++j) {
+			const uint32_t sj = rdlane(slot, j);
+			lower += (sj == slot && j < lane) ? 1u : 0u;
+			highest = (sj == slot && j > highest) ? j : highest;
+		}
+		wrong += ((got >> ((slot & 1u) << 4)) & 0xffffu) != lower;
+		wrong += win[slot] != highest;
+		wave_lds_fence();
+	}
+	if (wrong)
+		atomicAdd(bad, wrong);
+}
+
+/* ==========================================================================================
  * workload generator kernel (bench/test input; see workload_gen.h)
  * ======================================================================================== */
 extern "C" __global__ void __launch_bounds__(64)
@@ -3030,11 +3133,10 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
 constexpr uint32_t kChunkFragments = 32768; /* full fragments per GiB of a launch (the unit the workspace is sized in) */
 constexpr uint32_t kChunkFragmentsMax = 262144; /* short fragments (pages): as many as make up the same input, at most this per GiB */
 constexpr uint32_t kLaunchGibMax = 8;
-/* entries of the dense LDS table: 9 KiB + 1 KiB of filters = eight of gfx950's 1 280-byte LDS
- * granules, 16 fragments per CU (5 120 entries need nine: 14 per CU).  Fragments with more buckets
- * -- a quarter of G_text's, by a few dozen; most of urls.10K's, by a few hundred -- keep the rest
- * in their HBM spill-over. */
-constexpr uint32_t kDenseCapDefault = 4608;
+/* entries of the dense LDS table: 10 KiB = eight of gfx950's 1 280-byte LDS granules, 16 fragments
+ * per CU (until round 5, 4 608 entries + 1 KiB of conflict filters).  Fragments with more buckets
+ * -- urls.10K's at 4.5-5.5 k -- keep the rest in their HBM spill-over. */
+constexpr uint32_t kDenseCapDefault = 5120;
 constexpr uint32_t kDenseCap2 = 7168;       /* ... of the second dense launch (14 KiB; 10 per CU) */
 constexpr uint32_t kSpillCapDefault = 2048; /* buckets beyond the LDS table kept in HBM (4 KiB per fragment) */
 constexpr uint32_t kSampleMinDefault = 700; /* of 2048 sampled positions (text: ~1400, runs: ~300) */
@@ -3153,7 +3255,6 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	 * gets there (0.3 visits per step on text), and every KiB of LDS is worth ~4 % (one more
 	 * fragment per CU): 256 -> 128 entries costs 1 % at equal occupancy */
 	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 128u;
-	const uint32_t s_cap_hash = kn.s_entries ? kn.s_entries : 256u; /* (4 KiB pages: slot sharing is the rule) */
 	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
 	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
 	uint32_t dense_scratch = 0;
@@ -3174,21 +3275,14 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	if (P.tab == TAB_LDS_DENSE && cap >= slots)
 		P.tab = TAB_LDS_HASH; /* the dense table would be no smaller */
 	if (P.tab == TAB_LDS_HASH) {
-		P.lds0 = 1u << p;
-		filter_geometry(slots, s_cap_hash, false, &P.s_entries, &P.s_shift);
-		if (slots > P.s_entries) {
-			uint32_t bits = 0;
-			while ((1u << bits) < P.s_entries)
-				++bits;
-			P.s_shift = (uint32_t)(p - 1) - bits;
-		}
+		P.lds0 = 1u << p; /* (no filters: the LDS placements find slot sharing through the table) */
 	} else if (P.tab == TAB_LDS_DENSE) {
 		/* small fragments (pages): a table for every fragment there can be (`most`) leaves 25
 		 * pages per CU; few pages have more than 0.56 x that many buckets, so the first launch
 		 * takes a table of that size (32 pages per CU, the wave limit) and the second one, with
 		 * the full table, the pages that overflowed */
 		uint32_t cap_full = 0;
-		if (!kn.dense_cap && maxfrag < kFragment && cap == most && most >= 1536) {
+		if (!kn.dense_cap && maxfrag < kFragment && cap == most && 2 * most > kLdsPerCu / 32) {
 			cap_full = cap;
 			cap = ((most * 9 / 16) + 63) & ~63u;
 		}
@@ -3198,7 +3292,6 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		const uint32_t scratch = 10u * (slots >> 5);
 		dense_scratch = scratch;
 		P.lds0 = (2 * cap + 15) & ~15u;
-		filter_geometry(cap, s_cap, true, &P.s_entries, &P.s_shift);
 		P.fallback = (maxfrag > 3 && cap < (maxfrag - 3) / 2) || (kn.sample_min && maxfrag == kFragment);
 		P.sample_min = kn.sample_min;
 		/* fragments with more buckets than the first table get a second try with a larger one
@@ -3209,14 +3302,13 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		} else if (maxfrag == kFragment && kn.spill_cap) {
 			/* full fragments: the buckets beyond the LDS table go to HBM in the same launch */
 			P.spill_cap = kn.spill_cap;
-			P.fallback = cap + P.spill_cap < (maxfrag - 3) / 2 || kn.sample_min;
+			P.fallback = cap + P.spill_cap - kSpillFilterSlots < (maxfrag - 3) / 2 || kn.sample_min;
 		} else if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
 			P.cap2 = kDenseCap2;
 		}
 		if (P.cap2) {
 			P.lds0_2 = (2 * P.cap2 + 15) & ~15u;
-			filter_geometry(P.cap2, s_cap, true, &P.s_entries_2, &P.s_shift_2);
-			P.lds_bytes_2 = P.lds0_2 + P.s_entries_2 * 4 * (P.s_shift_2 ? 2 : 1);
+			P.lds_bytes_2 = P.lds0_2;
 			if (P.lds_bytes_2 < scratch)
 				P.lds_bytes_2 = scratch;
 		}
@@ -3296,6 +3388,41 @@ Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn,
 	W.tab_bytes = (uint64_t)W.chunk_frags * W.tab_stride;
 	W.total = W.cnt_bytes + W.rec_bytes + W.tab_bytes + 65536;
 	return W;
+}
+
+
+/* 0: the LDS serves one instruction's lanes in ascending order on this device (snappy_lds_order_probe);
+ * checked once per device and process, on the caller's stream (one small launch and a 4-byte copy) */
+int lds_order_checked(hipStream_t st)
+{
+	static std::mutex mu;
+	static int verdict[64]; /* 0 unknown, 1 good, -1 bad */
+	int dev = 0;
+	if (!hip_ok(hipGetDevice(&dev), "hipGetDevice") || dev < 0 || dev >= 64)
+		return CSNAPPY_HIP_E_RUNTIME;
+	std::lock_guard<std::mutex> lock(mu);
+	if (verdict[dev] == 0) {
+		uint32_t *d_bad = nullptr, h_bad = 1;
+		if (!hip_ok(hipMalloc(&d_bad, 4), "hipMalloc (LDS order probe)"))
+			return CSNAPPY_HIP_E_RUNTIME;
+		bool ok = hip_ok(hipMemsetAsync(d_bad, 0, 4, st), "hipMemsetAsync (LDS order probe)");
+		if (ok) {
+			hipLaunchKernelGGL(snappy_lds_order_probe, dim3(512), dim3(64), 0, st, d_bad);
+			ok = hip_ok(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (LDS order probe)") &&
+			     hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize (LDS order probe)");
+		}
+		(void)hipFree(d_bad);
+		if (!ok)
+			return CSNAPPY_HIP_E_RUNTIME;
+		verdict[dev] = h_bad == 0 ? 1 : -1;
+	}
+	if (verdict[dev] < 0) {
+		snprintf(g_last_error, sizeof(g_last_error),
+			 "this device's LDS does not serve the lanes of one instruction in ascending order "
+			 "(snappy_lds_order_probe): the parsers of this build cannot run on it");
+		return CSNAPPY_HIP_E_RUNTIME;
+	}
+	return 0;
 }
 
 } // namespace
@@ -3423,6 +3550,11 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return CSNAPPY_HIP_E_ARG;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const ParsePlan P = plan_parse(p, max_fragment(max_in_len), kn);
+	if (P.tab != TAB_GLOBAL) {
+		const int rc = lds_order_checked(st);
+		if (rc)
+			return rc;
+	}
 
 	CompressArgs A;
 	A.in = static_cast<const uint8_t *>(d_in);
