@@ -234,9 +234,86 @@ class GpuEngine:
         from csnappy_amd import shard
         return shard.compact(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt])[0]
 
-    def time_gather(self, prepared, d_out, b, cnt, dist, world):
+    def root_buffer(self, prepared, dist, world):
+        """Collective (8 B per rank), then rank 0's one allocation: the buffer the streams are
+        assembled in -- made before the ranks agree to enter the exchange, so that a root that has
+        no room for it costs the record its `gather` field instead of leaving seven ranks in isend."""
         from csnappy_amd import shard
-        return shard.time_gather_compacted(d_out, b, dist, world, cnt=cnt)
+        sizes = shard.exchange_sizes(prepared, dist, world)
+        return shard.root_buffer(sizes, prepared.device) if dist.get_rank() == 0 else None
+
+    def time_gather(self, prepared, root_out, d_out, b, cnt, dist, world):
+        from csnappy_amd import shard
+        return shard.time_gather_compacted(d_out, b, dist, world, cnt=cnt, dense=prepared, root_out=root_out)
+
+
+# The other BASELINE.json configurations, measured briefly behind the headline one (rank 0 of a 1-GPU
+# run) so that the driver's record holds them too: name -> (workload, GiB, what it stands for)
+OTHER_CONFIGS = {
+    "config3_urls_1gib_p16": ("urls", 1.0, "configs[2]: 1 GiB urls.10K-replicated, round trip"),
+    "config4_page_8gib_p13": ("page", 8.0, "configs[3]: zram-style 4 KiB pages, FRAGMENT mode, p=13 (one GPU's 8 GiB of it)"),
+    "config5_low_8gib_p16": ("low", 8.0, "configs[4]: low-entropy synthetic (one 8 GiB chunk of it)"),
+}
+
+
+def measure_other_configs(eng, steps, scale=1.0):
+    """A short round-trip measurement of each OTHER_CONFIGS entry on this GPU: `steps` timed steps
+    behind one checked step (every block round-trips, outside the timed region).  The record's
+    `value`, `config` and `roofline` stay the headline configuration's; this adds
+    {name: {value, compress_gibs, decompress_gibs, ratio, roofline_frac, ...}}."""
+    torch = eng.torch
+    res = {}
+    for name, (workload, gib, what) in OTHER_CONFIGS.items():
+        kind, seed, block, p, mode, desc = WORKLOADS[workload]
+        try:
+            nb = max(1, int(gib * scale * 2 ** 30) // block)
+            urls = open(os.path.join(ROOT, "tests", "golden", "urls.10K"), "rb").read() if kind < 0 else None
+            d_in = eng.generate(kind, seed, 0, nb, block, urls)
+            b = eng.batch([block] * nb)
+            d_out = eng.zeros(b.out_bytes, torch.uint8)
+            d_back = eng.zeros(nb * block, torch.uint8)
+            cap = eng.full(nb, block, torch.int32)
+            status = eng.full(nb, -99, torch.int32)
+            produced = eng.zeros(nb, torch.int32)
+
+            def step():
+                eng.compress(d_in, b, nb, d_out, p, mode)
+                eng.decompress(d_out, b, nb, d_back, cap, status, produced, mode)
+            step()
+            eng.sync()
+            ok = bool((status == 0).all().item()) and bool(torch.equal(d_back[:nb * block], d_in[:nb * block]))
+            comp = int(b.d_out_len[:nb].to(torch.int64).sum().item())
+            eng.timing(True)
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            eng.sync()
+            dt = (time.perf_counter() - t0) / steps
+            eng.timing(False)
+            kt = {k: ms / steps for k, (ms, _) in eng.kernel_times().items()}
+            n = nb * block
+            c_ms = kt["snappy_parse_fragments"] + kt["snappy_emit_blocks"]
+            d_ms = kt["snappy_decompress_blocks"]
+            gibs = lambda ms: round(n / (ms / 1e3) / 2 ** 30, 3) if ms > 0 else None
+            res[name] = {
+                "what": what, "workload": f"{nb * block / 2 ** 30:g} GiB of {desc}, {block}-byte blocks, "
+                                          f"{'STREAM' if mode == 0 else 'FRAGMENT'} mode, table power {p}",
+                "value": round(n / dt / 2 ** 30, 3), "unit": "GiB/s", "steps": steps,
+                "ms_per_step": round(dt * 1e3, 3), "round_trip_ok": ok,
+                "compress_gibs": gibs(c_ms), "decompress_gibs": gibs(d_ms),
+                "ratio": round(comp / n, 6),
+                "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+                # the compress operation's algorithmic bytes (N_in + C_out) over its kernels' time, of the 8 TB/s roof
+                "roofline_frac": round((n + comp) / (c_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if c_ms > 0 else None,
+                "roofline_frac_decompress": round((n + comp) / (d_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if d_ms > 0 else None,
+            }
+            del d_in, b, d_out, d_back, cap, status, produced
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must never take the headline line down
+            res[name] = {"what": what, "error": f"{type(e).__name__}: {e}"[:200]}
+        if hasattr(torch, "cuda") and torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    return res
 
 
 def parse_args(argv=None):
@@ -260,6 +337,12 @@ def parse_args(argv=None):
                     help="also time the RCCL gather of the compacted per-rank streams to rank 0 (reported "
                          "separately; never part of `value`).  Default: on when there is more than one rank")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=None,
+                    help="behind the headline measurement, measure the other BASELINE.json configurations briefly "
+                         "(3 steps each) and add them to the record as `other_configs`.  Default: on for the "
+                         "default 1-GPU text run, off otherwise")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
+    ap.add_argument("--other-scale", type=float, default=1.0, help=argparse.SUPPRESS)  # tests: shrink the other configs
     ap.add_argument("--engine", default=None, help=argparse.SUPPRESS)  # tests: module:Class standing in for GpuEngine
     return ap.parse_args(argv)
 
@@ -359,17 +442,31 @@ def run(args, eng, dist, rank, world):
         # The part that can fail on ONE rank -- allocations, the compaction -- runs first and on its own;
         # the ranks then agree (all_reduce MIN of an ok flag) and enter the exchange together or not at
         # all: a rank that raised before the collective would otherwise leave the others waiting in it.)
-        prepared, err = None, None
+        def agreed(err):
+            """True when no rank has an error; a collective that fails is an error too."""
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=eng.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return bool(ok.item())
+
+        prepared, root_out, err = None, None, None
         try:
-            prepared = eng.prepare_gather(d_out, b, chunks[-1][1])  # the last chunk's output
-        except Exception as e:  # noqa: BLE001 -- reported in the record, the measurement stands
-            err = f"{type(e).__name__}: {e}"[:200]
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=eng.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item():
-            gather = eng.time_gather(prepared, d_out, b, chunks[-1][1], dist, world)
-        else:
-            gather_error = err or "another rank could not prepare its stream"
+            try:
+                prepared = eng.prepare_gather(d_out, b, chunks[-1][1])  # the last chunk's output
+            except Exception as e:  # noqa: BLE001 -- reported in the record, the measurement stands
+                err = f"{type(e).__name__}: {e}"[:200]
+            if agreed(err):
+                # rank 0's assembly buffer: the one allocation only one rank makes, so it is made
+                # (and agreed on) before anybody posts a send
+                try:
+                    root_out = eng.root_buffer(prepared, dist, world)
+                except Exception as e:  # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"[:200]
+                if agreed(err):
+                    gather = eng.time_gather(prepared, root_out, d_out, b, chunks[-1][1], dist, world)
+            if gather is None:
+                gather_error = err or "another rank could not prepare its stream"
+        except Exception as e:  # noqa: BLE001 -- a collective itself failed (RCCL error): the line is still printed
+            gather_error = f"{type(e).__name__}: {e}"[:200]
 
     if rank != 0:
         return None
@@ -440,6 +537,14 @@ def run(args, eng, dist, rank, world):
         # (scaled by blocks, not by chunks: the last chunk may be a short one)
         out["value_with_gather"] = round(n_bytes * world / (t_max / args.steps
                                                             + gather["ms"] / 1e3 * nb / chunks[-1][1]) / 2 ** 30, 4)
+    want_other = args.other_configs if args.other_configs is not None else (
+        world == 1 and args.workload == "text" and args.gib == 1.0 and args.block is None and args.p is None)
+    if want_other and world == 1:
+        # the headline buffers are not needed any more: give their HBM back first
+        del d_in, d_out, d_back, cap, status, produced, b
+        if hasattr(torch, "cuda") and torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        out["other_configs"] = measure_other_configs(eng, 3, args.other_scale)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(kind, seed, block, p, mode, nb, args.cpu_seconds, urls)

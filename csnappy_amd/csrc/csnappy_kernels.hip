@@ -3130,6 +3130,7 @@ struct Timer {
 };
 
 constexpr uint32_t kLdsPerCu = 160 * 1024;
+constexpr uint32_t kLdsPerWorkgroupMax = kLdsPerCu; /* the most dynamic LDS one workgroup can ask for (gfx950: all of it) */
 constexpr uint32_t kChunkFragments = 32768; /* full fragments per GiB of a launch (the unit the workspace is sized in) */
 constexpr uint32_t kChunkFragmentsMax = 262144; /* short fragments (pages): as many as make up the same input, at most this per GiB */
 constexpr uint32_t kLaunchGibMax = 8;
@@ -3361,7 +3362,9 @@ struct Workspace {
 	uint32_t chunk_blocks, chunk_frags, rec_cap, tab_stride;
 };
 
-/* launch_gib: GiB of input one parser launch covers (1..kLaunchGibMax) */
+/* launch_gib: GiB of input one parser launch covers (1..kLaunchGibMax); 0: the floor -- launches of
+ * kChunkFragments fragments whatever their size (1 GiB of full fragments, 128 MiB of 4 KiB pages: what
+ * a caller with a small pooled scratch can afford; csnappy_hip_compress_workspace_size) */
 Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn, uint32_t launch_gib = 1)
 {
 	Workspace W;
@@ -3373,7 +3376,7 @@ Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn,
 	uint64_t cf = (uint64_t)kChunkFragments * kFragment / mf;
 	if (cf > kChunkFragmentsMax)
 		cf = kChunkFragmentsMax;
-	cf *= launch_gib;
+	cf = launch_gib ? cf * launch_gib : kChunkFragments;
 	uint64_t cb = cf / fpb;
 	if (cb < 1)
 		cb = 1;
@@ -3505,15 +3508,16 @@ void csnappy_hip_get_kernel_timing(float ms[4], uint32_t launches[4])
 
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len)
 {
-	return csnappy_hip_compress_workspace_size_for(nblocks, max_in_len, 1);
+	if (nblocks == 0)
+		return 65536;
+	return (size_t)plan_workspace(nblocks, max_in_len, knobs(), 0).total;
 }
 
 size_t csnappy_hip_compress_workspace_size_for(uint32_t nblocks, uint32_t max_in_len, uint32_t launch_gib)
 {
 	if (nblocks == 0)
 		return 65536;
-	if (launch_gib < 1)
-		launch_gib = 1;
+	/* (0: the floor, csnappy_hip_compress_workspace_size) */
 	if (launch_gib > kLaunchGibMax)
 		launch_gib = kLaunchGibMax;
 	return (size_t)plan_workspace(nblocks, max_in_len, knobs(), launch_gib).total;
@@ -3535,10 +3539,10 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return 0;
 	/* the largest launches the caller's workspace has room for (csnappy_hip_compress_workspace_size_for);
 	 * csnappy_hip_compress_workspace_size() -- launches of 1 GiB -- is the least that is accepted */
-	Workspace W = plan_workspace(nblocks, max_in_len, kn, 1);
+	Workspace W = plan_workspace(nblocks, max_in_len, kn, 0);
 	if (workspace_bytes < W.total || (reinterpret_cast<uintptr_t>(d_workspace) & 255))
 		return CSNAPPY_HIP_E_WORKSPACE;
-	for (uint32_t g = kLaunchGibMax; g > 1; --g) {
+	for (uint32_t g = kLaunchGibMax; g >= 1; --g) {
 		const Workspace Wg = plan_workspace(nblocks, max_in_len, kn, g);
 		if (Wg.total <= workspace_bytes) {
 			W = Wg;
@@ -3590,16 +3594,29 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 				 ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof)
 					       : reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean))
 			 : P.tab == TAB_LDS_HASH ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean) : k2;
-	if (!hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes),
-		    "hipFuncSetAttribute") ||
-	    (P.fallback &&
-	     !hip_ok(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.g_lds_bytes),
-		     "hipFuncSetAttribute")))
-		return CSNAPPY_HIP_E_RUNTIME;
-	if (P.cap2 && P.lds_bytes_2 > P.lds_bytes &&
-	    !hip_ok(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes_2),
-		    "hipFuncSetAttribute"))
-		return CSNAPPY_HIP_E_RUNTIME;
+	{
+		/* the kernels' dynamic-LDS limit is one attribute per kernel and process: raised once to the
+		 * most a workgroup can have, never per call (a call with a small table must not lower it
+		 * under another thread's launch) */
+		static std::once_flag once;
+		static bool attr_ok = false;
+		std::call_once(once, [] {
+			const void *ks[] = { reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean),
+					     reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof),
+					     reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean),
+					     reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
+					     reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof) };
+			attr_ok = true;
+			for (const void *k : ks)
+				attr_ok = attr_ok && hip_ok(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+										   (int)kLdsPerWorkgroupMax),
+							    "hipFuncSetAttribute");
+		});
+		if (!attr_ok)
+			return CSNAPPY_HIP_E_RUNTIME;
+		if (P.lds_bytes > kLdsPerWorkgroupMax || P.g_lds_bytes > kLdsPerWorkgroupMax || P.lds_bytes_2 > kLdsPerWorkgroupMax)
+			return CSNAPPY_HIP_E_ARG;
+	}
 
 	for (uint32_t b0 = 0; b0 < nblocks; b0 += W.chunk_blocks) {
 		const uint32_t nb = nblocks - b0 < W.chunk_blocks ? nblocks - b0 : W.chunk_blocks;

@@ -33,13 +33,17 @@ def dense_offsets(out_len):
     return off, int(lens.sum().item())
 
 
-def compact(d_out, d_out_off, d_out_len):
+def compact(d_out, d_out_off, d_out_len, into=None):
     """Pack the slot-strided compress output into one dense stream on the device.
+    into: a uint8 tensor of at least the stream's size to pack into (no allocation then).
     -> (dense uint8 tensor, int64 dense offsets)"""
     import torch
     from . import api
     off, total = api.dense_offsets(d_out_len) if d_out_len.is_cuda else dense_offsets(d_out_len)
-    dense = torch.empty(max(total, 1), dtype=torch.uint8, device=d_out.device)
+    if into is not None and into.numel() >= max(total, 1):
+        dense = into
+    else:
+        dense = torch.empty(max(total, 1), dtype=torch.uint8, device=d_out.device)
     api.compact_batch(d_out, d_out_off, d_out_len, off, dense)
     return dense[:total], off
 
@@ -60,19 +64,34 @@ def gather_streams(dense, dist, world, group=None):
     return [bufs[r][:sizes[r]] for r in range(world)], sizes
 
 
-def gather_to_root(dense, dist, world, root=0, group=None):
-    """Variable-size gather of the per-rank streams to `root` with grouped point-to-point
-    operations (ncclGroupStart/End under the nccl backend).  The size exchange is the only host
-    synchronisation.  -> (assembled uint8 tensor on root / None elsewhere, sizes list)"""
+def exchange_sizes(dense, dist, world, group=None):
+    """all_gather of the per-rank stream sizes (8 B per rank) -> list of ints."""
     import torch
-    rank = dist.get_rank(group)
     size = torch.tensor([dense.numel()], dtype=torch.int64, device=dense.device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    return [int(s.item()) for s in sizes]
+
+
+def root_buffer(sizes, device):
+    """The buffer `root` assembles the streams in (the one allocation of the gather that only one
+    rank makes: callers that must not hang make it BEFORE the ranks agree to enter the exchange)."""
+    import torch
+    return torch.empty(max(int(np.sum(sizes)), 1), dtype=torch.uint8, device=device)
+
+
+def gather_to_root(dense, dist, world, root=0, group=None, sizes=None, out=None):
+    """Variable-size gather of the per-rank streams to `root` with grouped point-to-point
+    operations (ncclGroupStart/End under the nccl backend).  The size exchange is the only host
+    synchronisation (skipped when the caller passes `sizes`); `out`: root's buffer, if the caller
+    made it already (root_buffer).  -> (assembled uint8 tensor on root / None elsewhere, sizes list)"""
+    rank = dist.get_rank(group)
+    if sizes is None:
+        sizes = exchange_sizes(dense, dist, world, group)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     if rank == root:
-        out = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, device=dense.device)
+        if out is None or out.numel() < max(int(offs[-1]), 1):
+            out = root_buffer(sizes, dense.device)
         out[int(offs[root]):int(offs[root + 1])] = dense
         ops = [dist.P2POp(dist.irecv, out[int(offs[r]):int(offs[r + 1])], r, group)
                for r in range(world) if r != root and sizes[r] > 0]
@@ -98,18 +117,20 @@ def gather_lengths(lens, counts, dist, world, group=None):
     return torch.cat([bufs[r][:counts[r]] for r in range(world)])
 
 
-def time_gather_compacted(d_out, b, dist, world, reps=3, cnt=None):
+def time_gather_compacted(d_out, b, dist, world, reps=3, cnt=None, dense=None, root_out=None):
     """Time compaction + the RCCL gather of the final stream (reported next to, never inside,
     the codec throughput).  cnt: the blocks of `b` that the last launch filled (a batch's last
-    chunk may be shorter than the descriptors; the lengths behind it are stale)."""
+    chunk may be shorter than the descriptors; the lengths behind it are stale).
+    dense / root_out: buffers made beforehand (this rank's stream, root's assembly buffer): the
+    timed loop then allocates nothing -- it packs into `dense` and receives into `root_out`."""
     import torch
     cnt = len(b.d_out_len) if cnt is None else cnt
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        dense, _ = compact(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt])
-        _, sizes = gather_to_root(dense, dist, world)
+        dense, _ = compact(d_out, b.d_out_off[:cnt], b.d_out_len[:cnt], into=dense)
+        _, sizes = gather_to_root(dense, dist, world, out=root_out)
     torch.cuda.synchronize()
     dist.barrier()
     dt = (time.perf_counter() - t0) / reps

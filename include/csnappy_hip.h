@@ -46,14 +46,15 @@ const char *csnappy_hip_last_error(void);
  * all <= max_in_len: per 32 KiB fragment the parser's 8-byte (literal, copy) records (one per four
  * input bytes at most), the 2-byte bucket ids of its positions (or its global-memory hash table),
  * 4 KiB for the table entries of buckets beyond the LDS table, and a record count.  A batch is
- * processed in launches of 1 GiB of input (32 768 full fragments, or as many pages), so the size
- * stops growing there: 4.1 GiB for 64 KiB blocks, 4.0 GiB for 4 KiB pages.  256-byte aligned base
- * required.  This is the LEAST the batch call accepts.
+ * processed in launches of at least 32 768 fragments, so the size stops growing there: 4.1 GiB for
+ * 64 KiB blocks (1 GiB of input per launch), 0.5 GiB for 4 KiB pages (128 MiB per launch).  256-byte
+ * aligned base required.  This is the LEAST the batch call accepts.
  *
- * ..._size_for(.., launch_gib): the scratch for launches of up to launch_gib (1..8) GiB.  A launch's
- * ramp and tail cost 5-11 % of a 1 GiB launch; a caller with a batch of several GiB and HBM to spare
- * (MI355X: 288 GB) passes a workspace of this size and the batch call uses the largest launches it
- * has room for (4 GiB launches: text -5 %, runs -11 %; 16.5 GiB of scratch).
+ * ..._size_for(.., launch_gib): the scratch for launches of up to launch_gib (1..8) GiB of input
+ * whatever the block size.  A launch's ramp and tail cost 5-11 % of a 1 GiB launch (and a tenth of a
+ * 128 MiB launch of pages); a caller with HBM to spare (MI355X: 288 GB) passes a workspace of this
+ * size and the batch call uses the largest launches it has room for (pages in 1 GiB launches: -13 %,
+ * 4.0 GiB of scratch; 4 GiB launches: text -5 %, runs -11 %; 16.5 GiB of scratch).
  */
 size_t csnappy_hip_compress_workspace_size(uint32_t nblocks, uint32_t max_in_len);
 size_t csnappy_hip_compress_workspace_size_for(uint32_t nblocks, uint32_t max_in_len, uint32_t launch_gib);

@@ -23,6 +23,9 @@ class OracleEngine:
         self.ms = {}
 
     def generate(self, kind, seed, first, nb, block, urls=None):
+        if kind < 0:
+            rep = np.frombuffer(urls, dtype=np.uint8)
+            return torch.from_numpy(rep[(np.arange(nb * block, dtype=np.int64) + first * block) % len(rep)].copy())
         return torch.from_numpy(api.generate_host(kind, seed, first, nb, block).copy())
 
     def batch(self, lens):
@@ -86,10 +89,17 @@ class OracleEngine:
         out, lens = d_out.numpy(), b.d_out_len.numpy()[:cnt]
         return torch.from_numpy(np.concatenate([out[int(o):int(o) + int(n)] for o, n in zip(b.out_off[:cnt], lens)]))
 
-    def time_gather(self, dense, d_out, b, cnt, dist_, world):
+    def root_buffer(self, dense, dist_, world):
+        if os.environ.get("CSNAPPY_TEST_FAIL_ROOT_BUFFER") and dist_.get_rank() == 0:
+            shard.exchange_sizes(dense, dist_, world)
+            raise MemoryError("injected by the test (root buffer)")
+        sizes = shard.exchange_sizes(dense, dist_, world)
+        return shard.root_buffer(sizes, dense.device) if dist_.get_rank() == 0 else None
+
+    def time_gather(self, dense, root_out, d_out, b, cnt, dist_, world):
         # ... then the product's own gather
         t0 = time.perf_counter()
-        rooted, sizes = shard.gather_to_root(dense, dist_, world)
+        rooted, sizes = shard.gather_to_root(dense, dist_, world, out=root_out)
         self.rooted = rooted
         return {"ms": round((time.perf_counter() - t0) * 1e3, 3), "gathered_bytes": int(np.sum(sizes)), "GBps": 0.0,
                 "what": "test stand-in"}

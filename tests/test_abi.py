@@ -117,6 +117,14 @@ def test_batch_api_rejects_bad_arguments_before_touching_the_device():
     assert L.csnappy_hip_compress_workspace_size(16384, 4096) < L.csnappy_hip_compress_workspace_size(16384, 65536)
     # a batch is parsed in launches of 1 GiB of input (32768 full fragments): the least workspace stops growing there
     assert L.csnappy_hip_compress_workspace_size(1 << 20, 65536) == L.csnappy_hip_compress_workspace_size(16384, 65536)
+    # 4 KiB pages: the least the call accepts is launches of 32768 pages (a caller's pooled scratch of about
+    # 0.5 GiB keeps working); launches of 1 GiB of pages are what ..._size_for(.., 1) sizes for
+    L.csnappy_hip_compress_workspace_size_for.restype = C.c_size_t
+    L.csnappy_hip_compress_workspace_size_for.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    floor = L.csnappy_hip_compress_workspace_size(1 << 22, 4096)
+    assert floor == L.csnappy_hip_compress_workspace_size(32768, 4096) and floor < 600 << 20
+    assert L.csnappy_hip_compress_workspace_size_for(1 << 22, 4096, 1) > 7 * floor
+    assert L.csnappy_hip_compress_workspace_size_for(1 << 20, 65536, 1) == L.csnappy_hip_compress_workspace_size(1 << 20, 65536)
 
 
 @pytest.mark.parametrize("name,value", [

@@ -120,3 +120,27 @@ def test_a_rank_that_cannot_prepare_its_stream_costs_the_gather_not_the_record()
     assert "gather" not in rec and "another rank" in rec["gather_error"]
     rec, _ = _bench_cli({"CSNAPPY_TEST_FAIL_PREPARE_ON_RANK": "0"})
     assert "gather" not in rec and "MemoryError" in rec["gather_error"]
+    # rank 0 has no room for the assembly buffer (the one allocation only one rank makes): it is made
+    # before the ranks agree to enter the exchange, so nobody is left in isend
+    rec, _ = _bench_cli({"CSNAPPY_TEST_FAIL_ROOT_BUFFER": "1"})
+    assert rec["n_ranks_seen"] == 2 and rec["value"] > 0
+    assert "gather" not in rec and "root buffer" in rec["gather_error"]
+
+
+@pytest.mark.timeout(300)
+def test_the_record_holds_the_other_baseline_configurations():
+    """`bench.py --gpus 1` measures BASELINE.json's other configurations briefly behind the headline
+    one; here with the CPU stand-in engine and the sizes shrunk, for the record's shape."""
+    args = bench.parse_args(["--gpus", "1", "--steps", "1", "--warmup", "1", "--gib", str(8 * BLOCK / 2 ** 30),
+                             "--no-cpu-baseline", "--verify-gib", "0", "--other-configs", "--other-scale",
+                             str(4 * BLOCK / 2 ** 30)])
+    rec = bench.run(args, OracleEngine(), None, 0, 1)
+    assert rec["value"] > 0 and "text" in rec["config"]["workload"].lower()
+    oc = rec["other_configs"]
+    assert set(oc) == {"config3_urls_1gib_p16", "config4_page_8gib_p13", "config5_low_8gib_p16"}
+    for name, r in oc.items():
+        assert "error" not in r, (name, r)
+        assert r["round_trip_ok"] is True and r["value"] > 0 and 0 < r["ratio"] < 1.2
+        for key in ("compress_gibs", "decompress_gibs", "roofline_frac", "kernel_ms", "workload", "steps"):
+            assert key in r, (name, key)
+    assert "4096-byte" in oc["config4_page_8gib_p13"]["workload"] and "FRAGMENT" in oc["config4_page_8gib_p13"]["workload"]

@@ -1025,6 +1025,32 @@ def test_launch_size_follows_the_workspace_and_does_not_change_the_bytes(torch, 
     del small, large
 
 
+def test_pages_with_the_least_workspace_the_call_accepts(torch, chk):
+    """csnappy_hip_compress_workspace_size is the floor -- launches of 32 768 fragments, 0.5 GiB of scratch
+    for 4 KiB pages (a caller's pooled scratch from before the launches grew) -- and the call takes it:
+    40 000 pages in two launches there, in one with the 1 GiB plan, the same bytes both ways."""
+    import hashlib
+    from csnappy_amd import shard
+    nb = 40000
+    d_in = api.generate(api.WG_PAGE, 0xC5A90004, 0, nb, 4096)
+    floor, roomy = api.Batch([4096] * nb, launch_gib=0), api.Batch([4096] * nb)
+    assert floor.d_ws.numel() == api.lib().csnappy_hip_compress_workspace_size(nb, 4096) < roomy.d_ws.numel()
+    d_out = torch.zeros(floor.out_bytes, dtype=torch.uint8, device="cuda")
+    res = []
+    for b in (floor, roomy):
+        d_out.zero_()
+        api.compress_batch(d_in, b.d_in_off, b.d_in_len, b.max_in_len, d_out, b.d_out_off, b.d_out_len, 13, api.FRAGMENT, b.d_ws)
+        torch.cuda.synchronize()
+        dense, _ = shard.compact(d_out, b.d_out_off, b.d_out_len)
+        res.append((b.d_out_len.cpu().numpy().copy(), hashlib.sha256(dense.cpu().numpy().tobytes()).hexdigest()))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    got, host = d_out.cpu().numpy(), api.generate_host(api.WG_PAGE, 0xC5A90004, 0, nb, 4096)
+    for k in (0, 32767, 32768, nb - 1):  # both sides of the floor plan's launch boundary
+        want = chk.compress_fragment(host[k * 4096:(k + 1) * 4096], 13)
+        o = int(floor.out_off[k])
+        assert bytes(got[o:o + int(res[0][0][k])]) == want, k
+
+
 def test_batch_calls_from_four_threads_on_their_own_streams(torch, chk):
     """include/csnappy_hip.h: the batch calls keep no state between calls and may be issued from
     several threads, each with its own buffers, workspace and stream.  Four threads, four streams,

@@ -17,8 +17,10 @@
  * It is also a program (main() below): one process, one GPU, one communicator of ONE rank -- all a
  * 1-GPU test box can run.  It compresses NBLOCKS blocks of G_text, gathers "all ranks'" streams
  * to the root and writes the assembled stream to the file named on the command line;
- * tests/test_gpu_parity.py builds it (gcc, against include/csnappy_hip.h, libcsnappy.so and the
- * librccl.so beside torch's HIP runtime), runs it and compares the file with the stream
+ * the Makefile builds it when ROCm's rccl.h and librccl.so are there (gcc, against
+ * include/csnappy_hip.h, libcsnappy.so and $(ROCM)/lib/librccl.so + libamdhip64.so -- a stand-alone C
+ * process uses ROCm's own runtime, not the one bundled with torch); tests/test_gpu_parity.py runs it
+ * and compares the file with the stream
  * csnappy_amd/shard.py compacts from the same batch.  With one rank the ncclAllGather and the
  * grouped (empty) exchange do run on the device; ncclSend/ncclRecv between ranks stay unmeasured
  * until an 8-GPU node sees this (the gloo tests cover the layout logic).
