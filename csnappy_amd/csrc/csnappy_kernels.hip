@@ -613,8 +613,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	 * keeps both filters (a returning atomic through memory would cost a round trip).
 	 * The add must not carry from the low half of a dword into the high one: entries are position |
 	 * check bit << 15 with positions < 32 754, at most 63 lower lanes -- a carry needs an entry of a
-	 * position >= kLatePos, and the steps that can see one flag every lane instead (the last one or
-	 * two of a full fragment; a flagged lane's visit is exact whatever flagged it). */
+	 * position >= kLatePos, and the steps behind one that may have inserted such a position (`late`: the
+	 * last one or two of a full fragment) flag every lane instead; a flagged lane's visit is exact
+	 * whatever flagged it.  Lanes without a bucket add 0 to entry 0 (no exec juggling). */
 	constexpr bool TW = !GTAB;
 	constexpr bool FILT = GTAB || SPILL;
 	/* TW + SPILL: the last kSpillFilterSlots entries of the LDS table are the spilled lanes' filter */
@@ -631,12 +632,23 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	const uint64_t lt_mask = (1ull << lane) - 1;
 	bool stuck = false;
 
+	/* An entry is position | check bit << 15 (one more bit of the position's hash: a candidate whose bit
+	 * differs cannot match and is not gathered).  memset(table, 0), csnappy_compress.c:501, makes an
+	 * empty slot mean position 0; the LDS tables (TW, no spill-over) are filled with position 0's entry
+	 * instead, so that a lane need not tell an empty slot from a written one. */
+	constexpr bool CHK0_INIT = TW && !SPILL;
+	uint32_t chk0 = 0;
+	if (n >= 4) {
+		uint32_t first4;
+		__builtin_memcpy(&first4, src, 4);
+		chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
+	}
 	if (n >= kMargin) {
-		/* memset(table, 0), csnappy_compress.c:501: an empty slot means position 0 */
 		const uint32_t zb = GTAB ? (1u << F.ws) >> 4 : DENSE ? 2 * dense_cap : 1u << F.ws;
+		const uint32_t zv = CHK0_INIT ? chk0 * 0x80008000u : 0u;
 		uint4 *z4 = reinterpret_cast<uint4 *>(smem);
 		for (uint32_t k = lane; k < (zb + 15) >> 4; k += 64)
-			z4[k] = make_uint4(0, 0, 0, 0);
+			z4[k] = make_uint4(zv, zv, zv, zv);
 		if (FILT) {
 			uint4 *s4 = reinterpret_cast<uint4 *>(S);
 			for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
@@ -682,9 +694,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t s = 1, q1 = 1;
 		uint32_t epoch = FT::kEpochs;
 		bool fin = false;
-		uint32_t first4;
-		__builtin_memcpy(&first4, src, 4);
-		const uint32_t chk0 = ((first4 * kHashMul) >> (shift - 1)) & 1u;
+		bool late = false; /* TW: an earlier step inserted a position >= kLatePos (see above) */
 
 		/* the lanes' 16 bytes and bucket ids are fetched one step ahead, as soon as the next
 		 * step's cursor is known */
@@ -751,8 +761,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			uint32_t cand, raw16 = 0;
 			uint64_t cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
 			uint32_t bumped = 0;
-			/* TW: this step may see an entry that an add could carry out of (see above) */
-			const bool late = TW && (sparse_c ? scan_pos(s, q1 + 62) : s + q1 + 61) >= kLatePos;
 			uint32_t key = 0, key2 = 0;
 			if (!TW) {
 				key = slot & smask;
@@ -766,9 +774,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				cand = written ? cand : 0u;
 			} else {
 				raw16 = tab[in_lds ? slot : 0u];
-				raw16 = in_lds ? raw16 : 0u;
-				if (in_lds && !late)
-					bumped = atomicAdd(&tab32[slot >> 1], 1u << ((slot & 1u) << 4));
+				if (!CHK0_INIT)
+					raw16 = in_lds ? raw16 : 0u;
+				const bool adds = in_lds && !late;
+				bumped = atomicAdd(&tab32[adds ? slot >> 1 : 0u], adds ? 1u << ((slot & 1u) << 4) : 0u);
 				cand = raw16;
 			}
 			if (SPILL && ballot64(spilled)) {
@@ -784,7 +793,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			 * the read-back (dense steps; lanes without a candidate read position 0 -- one
 			 * broadcast line; masking them off the load, here and in the spill-over gather, changes
 			 * nothing: measured in round 3) */
-			const bool maybe = tabbed && (cand ? cand >> 15 : chk0) == chk; /* the candidate can match at all */
+			/* the candidate can match at all */
+			const bool maybe = tabbed && (CHK0_INIT ? cand >> 15 : (cand ? cand >> 15 : chk0)) == chk;
 			cand &= 0x7fffu;
 			uint4 w4 = make_uint4(0, 0, 0, 0);
 			if (!sparse_c) {
@@ -863,10 +873,14 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					s = ip + 1;
 					q1 = 0;
 				}
+				if (TW)
+					late |= rdlane(pos_c, e_final) >= kLatePos;
 				place();
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
+				if (TW)
+					late |= p0 + 63 >= kLatePos;
 				/* behind the gather (loads return in order: in front of it, the gather would wait for
 				 * this too): touch the id lines two steps ahead -- the exact cursor is not known yet,
 				 * the lines are -- so that the next place() finds them in the cache (text 10.1 -> 9.8 ms
@@ -886,8 +900,12 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					pn_gathered += __builtin_popcountll(ballot64(maybe));
 					pn_flagged += __builtin_popcountll(cmask);
 				}
-				uint32_t mlen = maybe ? common_prefix16(xlo, xhi) : 0u;
-				const uint64_t matchmask = ballot64(mlen >= 4) & ~1ull;
+				/* (computed by every lane, then selected: as a conditional the compiler wraps it in an
+				 * exec-mask region -- three scalar instructions and a branch.  Lane 0 is insert-only.) */
+				uint32_t cp16 = common_prefix16(xlo, xhi);
+				asm volatile("" : "+v"(cp16));
+				uint32_t mlen = (maybe && lane != 0) ? cp16 : 0u;
+				const uint64_t matchmask = ballot64(mlen >= 4);
 				if (PROF)
 					pn_match4 += __builtin_popcountll(matchmask);
 				/* flagged lanes are stops of the chain like matches: what they hold is decided
@@ -898,12 +916,18 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				/* c = lane behind a copy: the next stop of the chain.  64: the re-match probe falls
 				 * outside the usable lanes; 65: none of the 33 probes behind the copy is a stop;
 				 * lane | 128: that stop is a special lane */
+				/* Lane 0 (insert-only, never a stop itself) holds the chain's FIRST stop: lanes 1 .. lim0
+				 * are what is left of the current scan's stride-1 probes, so it is the same search
+				 * with cl = 0 and that many probes (the scalar unit did this until round 5: a dozen
+				 * instructions of its own per step) */
+				const uint32_t lim0 = 33 - q1;
 				uint32_t nx;
 				{
 					const uint64_t rest = stopmask >> (cl & 63u);
-					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+					asm volatile("" : "+v"(fm));
 					const uint32_t j = cl + fm;
-					const bool in = fm <= 32 && j <= 63;
+					const bool in = fm <= (lane == 0 ? lim0 : 32u) && j <= 63;
 					const uint32_t sp = (uint32_t)(special >> (j & 63u)) & 1u;
 					nx = cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
 				}
@@ -917,14 +941,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						return 65u;
 					return j | (((uint32_t)(special >> j) & 1u) << 7);
 				};
-				/* the first segment: lanes 1 .. lim0 are what is left of the current scan's
-				 * stride-1 probes */
-				const uint32_t lim0 = 33 - q1;
-				uint32_t t;
-				{
-					const uint32_t i0 = stopmask ? first_lane(stopmask) : 64u;
-					t = (i0 <= lim0 && i0 <= 63) ? i0 | (((uint32_t)(special >> (i0 & 63u)) & 1u) << 7) : 65u;
-				}
+				uint32_t t = rdlane(nx, 0);
 				uint64_t taken = 0; /* lanes whose match is part of the chain */
 				tick(4); /* match lengths, next-stop table */
 				for (;;) {
