@@ -694,7 +694,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t s = 1, q1 = 1;
 		uint32_t epoch = FT::kEpochs;
 		bool fin = false;
-		bool late = false; /* TW: an earlier step inserted a position >= kLatePos (see above) */
+		uint32_t late = 0; /* TW: an earlier step inserted a position >= kLatePos (see above) */
 
 		/* the lanes' 16 bytes and bucket ids are fetched one step ahead, as soon as the next
 		 * step's cursor is known */
@@ -776,7 +776,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				raw16 = tab[in_lds ? slot : 0u];
 				if (!CHK0_INIT)
 					raw16 = in_lds ? raw16 : 0u;
-				const bool adds = in_lds && !late;
+				const bool adds = in_lds && late == 0;
 				bumped = atomicAdd(&tab32[adds ? slot >> 1 : 0u], adds ? 1u << ((slot & 1u) << 4) : 0u);
 				cand = raw16;
 			}
@@ -797,38 +797,37 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			const bool maybe = tabbed && (CHK0_INIT ? cand >> 15 : (cand ? cand >> 15 : chk0)) == chk;
 			cand &= 0x7fffu;
 			uint4 w4 = make_uint4(0, 0, 0, 0);
-			if (!sparse_c) {
-				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
-#if CSNAPPY_PARSE_NOSTORE == 4
-				CSNAPPY_FLUSH_PREC();
-#endif
-			}
-			const uint64_t tmask = ballot64(tabbed);
-			if (!TW) {
-				const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
-				cmask = ballot64(tabbed & FT::flags(fe1, fe2, slot, lane));
-			} else {
-				/* my half of the dword as the add found it: the entry + the lower lanes of my slot */
-				const uint32_t seen = (bumped >> ((slot & 1u) << 4)) & 0xffffu;
-				cmask = late ? tmask & ~1ull : ballot64(in_lds && seen != raw16);
-				if (SPILL && ballot64(spilled)) {
-					const uint32_t fe1 = S[key];
-					cmask |= ballot64(spilled & FT::flags(fe1, ~0u, slot, lane));
+			uint64_t tmask = 0;
+			/* the lanes with a bucket, and those that share it with a lower lane (behind the gather's
+			 * issue in either kind of step: the kinds are told apart ONCE per step) */
+			auto step_flags = [&]() {
+				tmask = ballot64(tabbed);
+				if (!TW) {
+					const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
+					cmask = ballot64(tabbed & FT::flags(fe1, fe2, slot, lane));
+				} else {
+					/* my half of the dword as the add found it: the entry + the lower lanes of my slot */
+					const uint32_t seen = (bumped >> ((slot & 1u) << 4)) & 0xffffu;
+					const uint64_t shared = ballot64(seen != raw16) & tmask;
+					cmask = late ? tmask & ~1ull : shared;
+					if (SPILL && ballot64(spilled)) {
+						const uint32_t fe1 = S[key];
+						cmask = (cmask & ~ballot64(spilled)) | ballot64(spilled & FT::flags(fe1, ~0u, slot, lane));
+					}
 				}
-			}
-			if (FILT && --epoch == 0) {
-				/* the tags' epoch field is about to wrap: start over with empty filters */
-				wave_lds_fence();
-				uint4 *s4 = reinterpret_cast<uint4 *>(S);
-				for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
-					s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
-				wave_lds_fence();
-				epoch = FT::kEpochs;
-			}
+				if (FILT && --epoch == 0) {
+					/* the tags' epoch field is about to wrap: start over with empty filters */
+					wave_lds_fence();
+					uint4 *s4 = reinterpret_cast<uint4 *>(S);
+					for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
+						s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
+					wave_lds_fence();
+					epoch = FT::kEpochs;
+				}
+			};
 			uint32_t touch_b = 0;
-			tick(2); /* filters + table */
 
-			uint32_t e_final;
+			uint32_t e_final = 0;
 			bool inside = false;
 			uint2 rec = make_uint2(0, 0);
 			bool rec_mine = false;
@@ -837,6 +836,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			if (sparse_c) {
 				/* ---- sparse step: the lanes are the next probes of the stride rule; it ends at its
 				 * first match, and in front of the first lane that shares a slot with an earlier one */
+				step_flags();
+				tick(2); /* filters + table */
 				const uint64_t imask = ~ballot64(valid_c);
 				const uint32_t c1 = cmask ? first_lane(cmask) : 64u;
 				const uint32_t v = imask ? first_lane(imask) : 64u;
@@ -874,13 +875,19 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					q1 = 0;
 				}
 				if (TW)
-					late |= rdlane(pos_c, e_final) >= kLatePos;
+					late |= (uint32_t)(rdlane(pos_c, e_final) >= kLatePos);
 				place();
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
+				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
+#if CSNAPPY_PARSE_NOSTORE == 4
+				CSNAPPY_FLUSH_PREC();
+#endif
+				step_flags();
+				tick(2); /* filters + table */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
 				if (TW)
-					late |= p0 + 63 >= kLatePos;
+					late |= (uint32_t)(p0 + 63 >= kLatePos);
 				/* behind the gather (loads return in order: in front of it, the gather would wait for
 				 * this too): touch the id lines two steps ahead -- the exact cursor is not known yet,
 				 * the lines are -- so that the next place() finds them in the cache (text 10.1 -> 9.8 ms
