@@ -622,7 +622,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	const uint32_t dense_cap = (TW && SPILL) ? A.dense_cap - kSpillFilterSlots : A.dense_cap;
 	uint32_t *S = reinterpret_cast<uint32_t *>(smem + (TW ? 2 * dense_cap : A.lds0));
 	const uint32_t s_entries = TW ? kSpillFilterEntries : A.s_entries;
-	uint32_t *S2 = S + s_entries;
 	const uint32_t smask = s_entries - 1;
 	const uint32_t s_shift = TW ? 0u : A.s_shift;
 	const bool two_filters = !TW && s_shift != 0;
@@ -762,13 +761,19 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			uint64_t cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
 			uint32_t bumped = 0;
 			uint32_t key = 0, key2 = 0;
+			uint32_t xold = 0;
 			if (!TW) {
-				key = slot & smask;
-				key2 = (slot >> s_shift) & smask;
-				/* slot sharing inside a step: two small filters; see FilterTag */
-				atomicMin(&S[key], FT::tag(epoch, slot, lane, tabbed));
-				if (two_filters)
-					atomicMin(&S2[key2], FT::tag(epoch, FT::kSlots - slot, lane, tabbed));
+				/* slot sharing inside a step, global table: ONE returning exchange on a small keyed
+				 * array (both filters' room).  The LDS serves the lanes in ascending order, so a lane
+				 * gets back the tag of the nearest LOWER lane with its key (or an older step's): of
+				 * this step and my slot -> flagged, exactly; of this step and another slot -> my slot
+				 * may hide behind it, flagged to be safe; of an older step -> no lower lane has my key.
+				 * (Until round 5: two atomic minima, two reads and thirty instructions of tag
+				 * arithmetic.)  The tag's epoch field is epoch - 1: never that of the ~0 fill. */
+				key = slot & ((two_filters ? 2 * s_entries : s_entries) - 1);
+				(void)key2;
+				if (tabbed)
+					xold = atomicExch(&S[key], ((epoch - 1) << (7 + 15)) | (slot << 7) | lane);
 				const bool written = tabbed && ((occ[slot >> 5] >> (slot & 31)) & 1u);
 				cand = gtab[written ? slot : 0u];
 				cand = written ? cand : 0u;
@@ -803,8 +808,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			auto step_flags = [&]() {
 				tmask = ballot64(tabbed);
 				if (!TW) {
-					const uint32_t fe1 = S[key], fe2 = two_filters ? S2[key2] : ~0u;
-					cmask = ballot64(tabbed & FT::flags(fe1, fe2, slot, lane));
+					cmask = ballot64((xold >> (7 + 15)) == epoch - 1) & tmask;
 				} else {
 					/* my half of the dword as the add found it: the entry + the lower lanes of my slot */
 					const uint32_t seen = (bumped >> ((slot & 1u) << 4)) & 0xffffu;
@@ -977,7 +981,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						 * bytes -- else the table value it already compared with. */
 						const uint32_t slot_i = rdlane(slot, i);
 						uint64_t same = ballot64(slot == slot_i) & tmask & ((1ull << i) - 1);
-						if (same) {
+						if (same && taken) { /* (no copy taken yet: every lane below was inserted) */
 							const uint64_t below = taken & lt_mask;
 							const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
 							const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
