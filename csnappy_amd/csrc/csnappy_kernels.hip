@@ -688,9 +688,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	/* (a 15-byte fragment has ip_limit 0: no probe ever happens, it is one literal like n < 15) */
 	if (n > kMargin) {
 		const uint32_t ip_limit = n - kMargin;
-		/* the cursor: scan start s, and q1 = 1 + index of the next scan probe; q1 == 0: the
-		 * re-match probe at s - 1 (a copy just ended there) comes first */
-		uint32_t s = 1, q1 = 1;
+		/* the cursor: q1 = 1 + index of the next probe of the current scan (q1 == 0: a copy just ended,
+		 * its re-match probe comes first), and pz = the position lane 0 of the next step takes -- the scan's
+		 * start is pz - q1 + 2 (only sparse steps need it) */
+		uint32_t pz = 0, q1 = 1;
 		uint32_t epoch = FT::kEpochs;
 		bool fin = false;
 		uint32_t late = 0; /* TW: an earlier step inserted a position >= kLatePos (see above) */
@@ -701,11 +702,12 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t pos = 0;
 		bool valid = false;
 		auto place = [&]() {
-			pos = s + q1 - 2 + lane;
+			pos = pz + lane;
 			valid = pos < ip_limit;
 			if (__builtin_expect(q1 > 32, 0)) {
 				/* sparse: the next 64 probes of the stride rule; a probe happens only if the
 				 * NEXT position is still <= ip_limit (:542-544) */
+				const uint32_t s = pz - q1 + 2;
 				pos = scan_pos(s, q1 - 1 + lane);
 				valid = scan_pos(s, q1 + lane) <= ip_limit;
 			}
@@ -746,7 +748,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			}
 			tick(1); /* wait for the step's own bytes and ids */
 			const bool sparse_c = q1 > 32;
-			const uint32_t p0 = s + q1 - 2; /* dense: position of lane 0 */
+			const uint32_t p0 = pz; /* dense: position of lane 0 */
 			const uint32_t pos_c = pos;
 			const bool valid_c = valid;
 			const uint32_t me0 = raw0, me1 = raw1, me2 = raw2, me3 = raw3;
@@ -859,8 +861,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					e_final = ulim - 1; /* (ulim == 0 cannot happen: lane 0 is never flagged, and an invalid lane 0 ended the scan before) */
 					if (ulim == v && v < 64)
 						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
-					else
+					else {
 						q1 += ulim;
+						pz += ulim;
+					}
 				} else {
 					const uint32_t i = first_lane(matchmask);
 					e_final = i;
@@ -875,7 +879,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					next_emit = ip;
 					if (ip >= ip_limit)
 						fin = true; /* :585-586 */
-					s = ip + 1;
+					pz = ip - 1;
 					q1 = 0;
 				}
 				if (TW)
@@ -1027,23 +1031,35 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				if (PROF)
 					pn_hops += __builtin_popcountll(taken);
 				const uint32_t emit0 = next_emit, nev0 = nev;
-				const bool any = taken != 0;
 				const uint32_t last = 63u - (uint32_t)__builtin_clzll(taken | 1);
-				const uint32_t c = rdlane(cl, last); /* (no copy: lane 0's, unused) */
-				const uint32_t ip = p0 + c;
-				const bool end_a = t == 64;
-				/* (masks, not ?: -- the compiler turns a chain of selects on the cursor into branches,
-				 * and a taken branch costs a lone wave four instructions' time) */
-				const uint32_t m_any = 0u - (uint32_t)any, m_a = 0u - (uint32_t)end_a;
-				const uint32_t lim = (m_any & (c + 32)) | (~m_any & lim0);
+				const uint32_t c = rdlane(cl, last); /* where the last copy ends (no copy: lane 0's, unused) */
+				/* Scalar selects on two conditions -- was a copy taken at all; did the last one leave the
+				 * usable lanes (t == 64) -- one compare each (as C the compiler makes them branches, or
+				 * three mask operations a select).  The next step's lane 0: the position in front of the
+				 * copy's end (its ip - 1 insert), else the last lane e this step probed; either way the
+				 * step after finds nothing to probe exactly when that position is the last one in front
+				 * of the scan limit (:543-544, :585-586). */
+				uint32_t lim, qq, ne;
+				asm("s_cmp_lg_u64 %3, 0\n\t"
+				    "s_cselect_b32 %0, %4, %5\n\t"
+				    "s_cselect_b32 %1, %6, %7\n\t"
+				    "s_cselect_b32 %2, %8, %9"
+				    : "=&s"(lim), "=&s"(qq), "=&s"(ne)
+				    : "s"(taken), "s"(c + 32), "s"(lim0), "s"(1 - c), "s"(q1), "s"(p0 + c), "s"(next_emit)
+				    : "scc");
 				const uint32_t e = min(lim, ulim - 1);
-				e_final = (m_a & last) | (~m_a & e);
-				const uint32_t fin_a = ip >= ip_limit; /* :585-586 */
-				const uint32_t fin_b = (uint32_t)(ulim <= lim) & (uint32_t)(ulim < 64);
-				fin = ((m_a & fin_a) | (~m_a & fin_b)) != 0;
-				next_emit = (m_any & ip) | (~m_any & next_emit);
-				q1 = ~m_a & ((m_any & (e + 1 - c)) | (~m_any & (q1 + e)));
-				s = (m_any & (ip + 1)) | (~m_any & s);
+				uint32_t adv, q1n;
+				asm("s_cmp_eq_u32 %3, 64\n\t"
+				    "s_cselect_b32 %0, %4, %5\n\t"
+				    "s_cselect_b32 %1, 0, %6\n\t"
+				    "s_cselect_b32 %2, %7, %5"
+				    : "=&s"(adv), "=&s"(q1n), "=&s"(e_final)
+				    : "s"(t), "s"(c - 1), "s"(e), "s"(qq + e), "s"(last)
+				    : "scc");
+				next_emit = ne;
+				q1 = q1n;
+				pz = p0 + adv;
+				fin = pz + 1 >= ip_limit;
 				/* the cursor of the next step is known: fetch its bytes now (after the last step the
 				 * loads are harmless: an invalid lane reads position 0) */
 				place();

@@ -6,7 +6,7 @@ tag=$1; shift
 out=gpurun_out/insts_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 2 --warmup 1 --no-cpu-baseline $*"
+args="--steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $*"
 i=0
 for grp in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))

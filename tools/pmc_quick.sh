@@ -6,7 +6,7 @@ tag=$1; ctrs=$2; shift 2
 out=gpurun_out/pmcq_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout ${PMCQ_TIMEOUT:-150} rocprofv3 --pmc $ctrs --output-format csv -d $out/g -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify-gib 0 "$@" > $out/bench.json 2> $out/bench.err
+timeout ${PMCQ_TIMEOUT:-150} rocprofv3 --pmc $ctrs --output-format csv -d $out/g -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --verify-gib 0 "$@" > $out/bench.json 2> $out/bench.err
 python3 - "$out" > gpurun_out/pmcq_$tag.txt <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

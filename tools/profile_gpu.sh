@@ -11,7 +11,7 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 3 --warmup 1 --no-cpu-baseline $*"
+args="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs $*"
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py $args > $out/bench_stats.json 2> $out/bench_stats.err
 timeout 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 bench.py $args > $out/bench_fetch.json 2> $out/bench_fetch.err
 timeout 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 bench.py $args > $out/bench_write.json 2> $out/bench_write.err
