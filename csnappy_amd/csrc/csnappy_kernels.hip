@@ -944,7 +944,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					const uint32_t j = cl + fm;
 					const bool in = fm <= (lane == 0 ? lim0 : 32u) && j <= 63;
 					const uint32_t sp = (uint32_t)(special >> (j & 63u)) & 1u;
-					nx = cl >= ulim ? 64u : in ? j | (sp << 7) : 65u;
+					uint32_t inner = in ? j | (sp << 7) : 65u;
+					asm volatile("" : "+v"(inner)); /* (a select below, not an exec-mask region around the above) */
+					nx = cl >= ulim ? 64u : inner;
 				}
 				auto scalar_next = [&](uint32_t cc) -> uint32_t {
 					if (cc >= ulim)
@@ -956,23 +958,30 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						return 65u;
 					return j | (((uint32_t)(special >> j) & 1u) << 7);
 				};
-				uint32_t t = rdlane(nx, 0);
+				uint32_t t = 0; /* (the walk starts AT lane 0, whose entry is the first stop) */
 				uint64_t taken = 0; /* lanes whose match is part of the chain */
 				tick(4); /* match lengths, next-stop table */
-				for (;;) {
-					/* plain matches: hop from match to match (unrolling this loop four times was
-					 * measured in round 3: no gain) */
+				/* plain matches: hop from match to match (unrolling this loop four times was
+				 * measured in round 3: no gain) */
+	/* (one block, the mark in FRONT of the v_readlane: the mark, the compare, the move and the branch
+	 * are then the four wait states the next v_readlane's lane select needs, and the mark is the one
+	 * the first v_readlane needs behind the vector instruction that wrote nx -- written apart, the
+	 * compiler pays a wait state of its own inside the loop) */
 #define CSNAPPY_HOP()                                                                              \
 	{                                                                                          \
-		const uint32_t i = t;                                                              \
-		t = rdlane(nx, i);                                                                 \
-		asm("s_bitset1_b64 %0, %1" : "+s"(taken) : "s"(i)); /* taken |= 1ull << i */       \
+		uint32_t tn;                                                                       \
+		asm volatile("s_bitset1_b64 %0, %2\n\tv_readlane_b32 %1, %3, %2"                   \
+			     : "+s"(taken), "=&s"(tn) : "s"(t), "v"(nx)); /* taken |= 1ull << t; tn = nx[t] */ \
+		t = tn;                                                                            \
 	}
-					while (t < 64)
-						CSNAPPY_HOP();
-#undef CSNAPPY_HOP
-					if (t < 128)
-						break;
+				/* (the walk of a step without special lanes -- four steps in five -- is this loop alone:
+				 * written as the head of the loop below it dragged that loop's carried copies of the
+				 * lanes' match length, end and candidate into every step) */
+				do {
+					CSNAPPY_HOP();
+				} while (t < 64);
+				taken &= ~1ull; /* (lane 0 is where the walk starts, not a match) */
+				while (__builtin_expect(t >= 128, 0)) {
 					const uint32_t i = t & 63u;
 					uint32_t L = rdlane(mlen, i);
 					if (PROF)
@@ -1008,6 +1017,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 							const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
 							const uint32_t i2 = m ? first_lane(m) : 64u;
 							t = (i2 > lim_cur || i2 > 63) ? 65u : i2 | (((uint32_t)(special >> (i2 & 63u)) & 1u) << 7);
+							while (t < 64)
+								CSNAPPY_HOP();
 							continue;
 						}
 					}
@@ -1021,7 +1032,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					}
 					taken |= 1ull << i;
 					t = scalar_next(i + L);
+					while (t < 64)
+						CSNAPPY_HOP();
 				}
+#undef CSNAPPY_HOP
 				/* ---- where the chain left the step (selects, no branches: this is scalar code) ----
 				 * t == 64: the last copy ends at or behind the usable lanes: re-match probe next
 				 * (:585-594).  t == 65: the current window (the 33 probes behind the last copy, or what
