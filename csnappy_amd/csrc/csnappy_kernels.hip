@@ -23,7 +23,8 @@
  *   - compress: one wave per 32 KiB fragment reproduces the reference's sequential probe loop
  *     exactly, 64 consecutive positions per step: every lane hashes its 4 bytes, gathers the
  *     table entry, measures a lane-local match length against its candidate; a lane that shares
- *     a hash slot with an earlier lane of the step (the only way its table read could be stale)
+ *     a hash slot with an earlier lane of the step (the only way its table read could be stale;
+ *     found with one returning LDS add on the entry, whose lanes the LDS serves in order)
  *     is flagged and resolved from that lane's registers if the chain of copies -- followed on
  *     the scalar unit -- ever probes it.  The table lives in LDS, indexed by dense bucket ids a
  *     prologue of the same wave assigns (only slots hit twice can matter); the window is read
@@ -59,9 +60,6 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
 #ifndef CSNAPPY_PARSE_NTLOAD
 #define CSNAPPY_PARSE_NTLOAD 1
 #endif
-#ifndef CSNAPPY_PARSE_NOSTORE
-#define CSNAPPY_PARSE_NOSTORE 4
-#endif
 #ifndef CSNAPPY_PARSE_NOSPILLSTORE
 #define CSNAPPY_PARSE_NOSPILLSTORE 0
 #endif
@@ -82,12 +80,11 @@ struct CompressArgs {
 	uint32_t fpb;       /* fragments per block (upper bound) */
 	uint32_t rec_cap;
 	uint32_t tab_stride;
-	uint32_t lds0;      /* LDS bytes in front of the conflict filters (table / occupancy bitmap) */
+	uint32_t lds0;      /* global-table kernel: LDS bytes in front of its keyed array (the occupancy bitmap) */
 	uint32_t dense_cap; /* entries of the dense LDS table */
 	uint32_t spill_cap; /* buckets beyond those: a per-fragment table in HBM behind the ids (0 = none) */
 	uint32_t spill_off; /* its byte offset inside the fragment's `tabs` region */
-	uint32_t s_entries; /* conflict-filter entries per filter (power of two) */
-	uint32_t s_shift;   /* second filter's key bits start here; 0 = one filter only */
+	uint32_t s_entries; /* global-table kernel: keys of the array its lanes find slot sharing with (power of two) */
 	uint32_t only_unparsed; /* skip fragments that already have records (second and later launches) */
 	uint32_t max_in_len; /* the caller's bound on in_len[]: a longer block is refused (out_len = 0xffffffff) */
 	uint32_t emit_wave_per_block, emit_blocks; /* emit: one wave per block (fpb == 1, small blocks) */
@@ -256,7 +253,7 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
  * LDS has one uint16 entry per such bucket (~4.6 k on URL-like text, ~1 k on runs) and is indexed
  * by the id, which the lanes load with their 16 input bytes.  Same slots, same contents, same
  * order of updates as the reference's table -- only the slots nobody can ever read are gone.
- * The LDS table has 4 608 entries (9 KiB + 1 KiB of filters = 16 fragments per CU); a fragment
+ * The LDS table has 5 120 entries (10 KiB = 16 fragments per CU); a fragment
  * with up to 2 048 buckets more keeps those in a small table in HBM behind its ids (SPILL), and
  * one with still more is handed to a second launch that keeps the full 2^p-byte table in global
  * memory (TAB_GLOBAL); tables of <= 8 KiB are simply indexed by the hash (TAB_LDS_HASH, no
@@ -320,40 +317,31 @@ DEVINL uint2 pack_record(uint32_t lit_start, uint32_t base, uint32_t cnd, uint32
  *     the insert mask is only built when there is one.
  *   - block descriptors are read once, before the prologue's stores, so they stay scalar loads.
  * ======================================================================================== */
-/* Conflict filters.  A lane whose slot is also the slot of a LOWER lane
- * of the step cannot trust its table read ("flagged").  Two small arrays in LDS, keyed by different
- * bits of the slot, receive with atomicMin a tag {epoch, slot, lane}; the epoch counts down, so
- * tags of earlier steps never win and nothing is cleared between steps.  Within a step the
- * smallest tag of a key is that of the smallest SLOT among the lanes sharing the key, lowest lane
- * first: a lane that reads its own slot back knows exactly whether a lower lane shares it.  The
- * second array takes the slots in reverse order, so it settles the lanes with the largest slot
- * of a key.  A lane that neither array settles (a smaller slot shares its first key AND a larger
- * one its second) is flagged to be safe.  (Round 2 compared lane numbers only: every collision of
- * two keys was a false alarm -- 3.4 lanes per 64-position step of text.) */
-/* SB = bits of a slot: 13 for dense ids, 15 for hashes (the full table in global memory, or in
- * LDS); the epoch gets what is left of 32 bits beside them and 7 bits of lane */
+/* Tags of the small keyed arrays two kinds of lanes still find slot sharing with (parse_lean, "TW": the
+ * lanes of a table in LDS find it through the table itself).  A tag is {epoch, slot, lane}; the epoch
+ * counts down, so tags of earlier steps never win an atomicMin and nothing is cleared between steps.
+ *   - the lanes of a fragment whose bucket lies in the HBM spill-over: one array, atomicMin + read.  The
+ *     smallest tag of a key is that of the smallest SLOT among the lanes sharing the key, lowest lane
+ *     first: a lane that reads its own slot back knows exactly whether a lower lane shares it; a lane
+ *     that reads another slot is flagged to be safe (they are few: that is rare);
+ *   - the global-table kernel: one returning exchange (see there).
+ * SB = bits of a slot: 13 for dense ids, 15 for hashes; the epoch gets what is left of 32 bits beside
+ * them and 7 bits of lane. */
 template <int SB> struct FilterTag {
 	static constexpr uint32_t kSlots = (1u << SB) - 1;         /* largest slot */
-	static constexpr uint32_t kEpochs = (1u << (25 - SB)) - 1; /* steps between two clearings of the filters */
-	static DEVINL uint32_t tag(uint32_t epoch, uint32_t slot_field, uint32_t vlane, bool tabbed)
+	static constexpr uint32_t kEpochs = (1u << (25 - SB)) - 1; /* steps between two clearings of the array */
+	static DEVINL uint32_t tag(uint32_t epoch, uint32_t slot, uint32_t vlane, bool takes_part)
 	{
-		return tabbed ? (epoch << (7 + SB)) | (slot_field << 7) | vlane : ~0u;
+		return takes_part ? (epoch << (7 + SB)) | (slot << 7) | vlane : ~0u;
 	}
-	/* e1, e2: what the two arrays hold for my keys after the step's atomics (e2 = ~0: one array only) */
-	static DEVINL bool flags(uint32_t e1, uint32_t e2, uint32_t slot, uint32_t vlane);
+	/* e: what the array holds for my key after the step's atomicMin */
+	static DEVINL bool flags(uint32_t e, uint32_t slot, uint32_t vlane)
+	{
+		const bool settled = ((e >> 7) & kSlots) == slot;
+		/* (lane 0 has no lower lane; a sparse step that is cut in front of its first lane would never end) */
+		return (vlane != 0) & (settled ? (e & 127u) < vlane : true);
+	}
 };
-
-template <int SB> DEVINL bool FilterTag<SB>::flags(uint32_t e1, uint32_t e2, uint32_t slot, uint32_t vlane)
-{
-	constexpr uint32_t kFilterSlots = kSlots;
-	/* (bitwise, not short-circuit: with branches the compiler reads the second array only after it
-	 * has seen the first one's value -- two dependent LDS round trips on every step) */
-	const bool settled1 = ((e1 >> 7) & kFilterSlots) == slot;
-	const bool settled2 = ((e2 >> 7) & kFilterSlots) == kFilterSlots - slot;
-	const bool low1 = (e1 & 127u) < vlane, low2 = (e2 & 127u) < vlane;
-	/* (lane 0 has no lower lane; a sparse step that is cut in front of its first lane would never end) */
-	return (vlane != 0) & ((settled1 & low1) | (!settled1 & settled2 & low2) | (!settled1 & !settled2));
-}
 
 struct Frag {
 	const uint8_t *src; /* the fragment's input */
@@ -621,10 +609,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	/* TW + SPILL: the last kSpillFilterSlots entries of the LDS table are the spilled lanes' filter */
 	const uint32_t dense_cap = (TW && SPILL) ? A.dense_cap - kSpillFilterSlots : A.dense_cap;
 	uint32_t *S = reinterpret_cast<uint32_t *>(smem + (TW ? 2 * dense_cap : A.lds0));
-	const uint32_t s_entries = TW ? kSpillFilterEntries : A.s_entries;
+	const uint32_t s_entries = TW ? kSpillFilterEntries : A.s_entries; /* keys of that array (a power of two) */
 	const uint32_t smask = s_entries - 1;
-	const uint32_t s_shift = TW ? 0u : A.s_shift;
-	const bool two_filters = !TW && s_shift != 0;
 
 	uint32_t nev = 0;       /* records written */
 	uint32_t next_emit = 0; /* csnappy_compress.c:496 */
@@ -650,7 +636,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			z4[k] = make_uint4(zv, zv, zv, zv);
 		if (FILT) {
 			uint4 *s4 = reinterpret_cast<uint4 *>(S);
-			for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
+			for (uint32_t k = lane; k < (s_entries >> 2); k += 64)
 				s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 		}
 		wave_lds_fence();
@@ -729,7 +715,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		place();
 
 		uint32_t guard = 0; /* every step probes or inserts at least one new position: a logic error must not hang the GPU */
-#if CSNAPPY_PARSE_NOSTORE == 4
 		/* the previous step's records, stored BEHIND this step's candidate gather: gfx9 counts loads and
 		 * stores in one vmcnt, so a store issued in front of the gather would have to be acknowledged
 		 * before the gather's wait ends.  Every lane stores, the lanes without a record into the last slot
@@ -738,7 +723,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint2 prec = make_uint2(0, 0);
 		uint32_t prec_idx = A.rec_cap - 1;
 #define CSNAPPY_FLUSH_PREC() (*reinterpret_cast<unsigned long long *>(R + prec_idx) = *reinterpret_cast<unsigned long long *>(&prec))
-#endif
 		while (!fin && ++guard <= n) {
 			tick(0); /* (rest of the previous step: commit) */
 			if (PROF) {
@@ -762,18 +746,17 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			uint32_t cand, raw16 = 0;
 			uint64_t cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
 			uint32_t bumped = 0;
-			uint32_t key = 0, key2 = 0;
+			uint32_t key = 0;
 			uint32_t xold = 0;
 			if (!TW) {
 				/* slot sharing inside a step, global table: ONE returning exchange on a small keyed
-				 * array (both filters' room).  The LDS serves the lanes in ascending order, so a lane
+				 * array.  The LDS serves the lanes in ascending order, so a lane
 				 * gets back the tag of the nearest LOWER lane with its key (or an older step's): of
 				 * this step and my slot -> flagged, exactly; of this step and another slot -> my slot
 				 * may hide behind it, flagged to be safe; of an older step -> no lower lane has my key.
 				 * (Until round 5: two atomic minima, two reads and thirty instructions of tag
 				 * arithmetic.)  The tag's epoch field is epoch - 1: never that of the ~0 fill. */
-				key = slot & ((two_filters ? 2 * s_entries : s_entries) - 1);
-				(void)key2;
+				key = slot & smask;
 				if (tabbed)
 					xold = atomicExch(&S[key], ((epoch - 1) << (7 + 15)) | (slot << 7) | lane);
 				const bool written = tabbed && ((occ[slot >> 5] >> (slot & 31)) & 1u);
@@ -818,14 +801,14 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					cmask = late ? tmask & ~1ull : shared;
 					if (SPILL && ballot64(spilled)) {
 						const uint32_t fe1 = S[key];
-						cmask = (cmask & ~ballot64(spilled)) | ballot64(spilled & FT::flags(fe1, ~0u, slot, lane));
+						cmask = (cmask & ~ballot64(spilled)) | ballot64(spilled & FT::flags(fe1, slot, lane));
 					}
 				}
 				if (FILT && --epoch == 0) {
 					/* the tags' epoch field is about to wrap: start over with empty filters */
 					wave_lds_fence();
 					uint4 *s4 = reinterpret_cast<uint4 *>(S);
-					for (uint32_t k = lane; k < (((two_filters ? 2 : 1) * s_entries) >> 2); k += 64)
+					for (uint32_t k = lane; k < (s_entries >> 2); k += 64)
 						s4[k] = make_uint4(~0u, ~0u, ~0u, ~0u);
 					wave_lds_fence();
 					epoch = FT::kEpochs;
@@ -850,9 +833,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t ulim = min(c1, v);
 				const bool gathered = lane < ulim && maybe;
 				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
-#if CSNAPPY_PARSE_NOSTORE == 4
 				CSNAPPY_FLUSH_PREC();
-#endif
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
 				const uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
@@ -888,9 +869,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
 				__builtin_memcpy(&w4, src + (maybe ? cand : 0u), 16);
-#if CSNAPPY_PARSE_NOSTORE == 4
 				CSNAPPY_FLUSH_PREC();
-#endif
 				step_flags();
 				tick(2); /* filters + table */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
@@ -1104,21 +1083,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
 			if (PROF && sparse_c)
 				pn_sparse++;
-#if CSNAPPY_PARSE_NOSTORE == 4
 			prec = rec;
 			prec_idx = rec_mine ? rec_idx : A.rec_cap - 1;
-#elif CSNAPPY_PARSE_NOSTORE == 2
-			if (rec_mine)
-				R[rec_idx] = rec;
-#elif CSNAPPY_PARSE_NOSTORE == 3
-			/* every lane stores: the lanes without a record into the last slot of the fragment's
-			 * record region, which no record can reach */
-			*reinterpret_cast<unsigned long long *>(R + (rec_mine ? rec_idx : A.rec_cap - 1)) = *reinterpret_cast<unsigned long long *>(&rec);
-#elif !CSNAPPY_PARSE_NOSTORE /* (1: timing experiment only: wrong output) */
-			if (rec_mine)
-				__builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&rec),
-							    reinterpret_cast<unsigned long long *>(R + rec_idx));
-#endif
 			/* commit table[slot] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			bool commit = lane <= e_final && !inside && tabbed;
@@ -1163,10 +1129,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				spill[slot - dense_cap] = (uint16_t)mine16;
 			wave_lds_fence();
 		}
-#if CSNAPPY_PARSE_NOSTORE == 4
 		CSNAPPY_FLUSH_PREC();
 #undef CSNAPPY_FLUSH_PREC
-#endif
 		stuck = !fin;
 	}
 
@@ -1177,7 +1141,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		++nev;
 	}
 	if (lane == 0)
-		A.rec_cnt[F.c] = CSNAPPY_PARSE_NOSTORE == 1 ? 0u : stuck ? kNoRecords : nev; /* (never parsed: the emit kernel reports the block as failed) */
+		A.rec_cnt[F.c] = stuck ? kNoRecords : nev; /* (never parsed: the emit kernel reports the block as failed) */
 	if (PROF && lane == 0) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 		atomicAdd(&A.prof[0], t_end - pt_begin);
@@ -3223,7 +3187,7 @@ uint32_t record_cap(uint32_t n)
  * value makes every batch call fail with CSNAPPY_HIP_E_ARG):
  *   CSNAPPY_HIP_TABLE      auto | hash | dense | global   where the hash table lives
  *   CSNAPPY_HIP_DENSE_CAP  256..16384 (multiple of 64)    entries of the dense LDS table
- *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        entries per conflict filter
+ *   CSNAPPY_HIP_S_ENTRIES  64..4096 (power of two)        global-table kernel: half the keys of its exchange array
  *   CSNAPPY_HIP_WGS_PER_CU 1..32                          cap on fragments in flight per CU
  *   CSNAPPY_HIP_SAMPLE_MIN 0..2048                        dense placement: sampled-distinct threshold
  *                                                         below which a fragment takes the global table
@@ -3284,26 +3248,13 @@ const Knobs &knobs()
 /* Launch geometry of the parser for table power p and fragments of <= maxfrag bytes. */
 struct ParsePlan {
 	int tab;            /* TAB_* of the first launch */
-	uint32_t lds0, lds_bytes, dense_cap, s_entries, s_shift;
+	uint32_t lds0, lds_bytes, dense_cap, s_entries;
 	uint32_t sample_min;
-	uint32_t cap2, lds0_2, lds_bytes_2, s_entries_2, s_shift_2; /* second dense launch (0 = none) */
+	uint32_t cap2, lds0_2, lds_bytes_2; /* second dense launch (0 = none) */
 	uint32_t spill_cap; /* dense: buckets beyond the LDS table, kept in HBM (full fragments only) */
 	bool fallback;      /* a TAB_GLOBAL launch follows for fragments the dense table cannot hold */
-	uint32_t g_lds0, g_lds_bytes, g_s_entries, g_s_shift;
+	uint32_t g_lds0, g_lds_bytes, g_keys; /* global-table kernel: occupancy bitmap, all of its LDS, keys of its exchange array */
 };
-
-void filter_geometry(uint32_t slots, uint32_t s_cap, bool dense, uint32_t *s_entries, uint32_t *s_shift)
-{
-	*s_entries = slots < s_cap ? slots : s_cap;
-	if (*s_entries < 64)
-		*s_entries = 64;
-	uint32_t bits = 0;
-	while ((1u << bits) < *s_entries)
-		++bits;
-	/* a second filter on other bits of the slot when one filter cannot be exact (the dense parser
-	 * is compiled for two filters: it always gets both) */
-	*s_shift = dense ? bits : (uint32_t)0;
-}
 
 ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 {
@@ -3374,20 +3325,16 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	}
 	/* global-table geometry (first launch when forced, else the fallback) */
 	P.g_lds0 = ((1u << p) >> 4) < 16 ? 16 : (1u << p) >> 4;
-	filter_geometry(slots, s_cap, false, &P.g_s_entries, &P.g_s_shift);
-	if (slots > P.g_s_entries) {
-		uint32_t bits = 0;
-		while ((1u << bits) < P.g_s_entries)
-			++bits;
-		P.g_s_shift = (uint32_t)(p - 1) - bits;
-	}
-	P.g_lds_bytes = P.g_lds0 + P.g_s_entries * 4 * (P.g_s_shift ? 2 : 1);
+	/* (its keyed array: 256 keys = 1 KiB unless the knob says otherwise; powers of two all) */
+	P.g_keys = 2 * s_cap < slots ? 2 * s_cap : slots;
+	if (P.g_keys < 64)
+		P.g_keys = 64;
+	P.g_lds_bytes = P.g_lds0 + P.g_keys * 4;
 	if (P.tab == TAB_GLOBAL) {
 		P.lds0 = P.g_lds0;
-		P.s_entries = P.g_s_entries;
-		P.s_shift = P.g_s_shift;
+		P.s_entries = P.g_keys;
 	}
-	P.lds_bytes = P.lds0 + P.s_entries * 4 * (P.s_shift ? 2 : 1);
+	P.lds_bytes = P.lds0 + P.s_entries * 4;
 	if (P.tab == TAB_LDS_DENSE && P.lds_bytes < dense_scratch)
 		P.lds_bytes = dense_scratch;
 	if (kn.wgs_per_cu) {
@@ -3684,15 +3631,12 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		t.start();
 		A.lds0 = P.lds0;
 		A.s_entries = P.s_entries;
-		A.s_shift = P.s_shift;
 		A.only_unparsed = 0;
 		if (!hip_ok(hipLaunchKernel(k1, dim3(nb * fpb), dim3(64), args, P.lds_bytes, st),
 			    "launch snappy_parse_fragments"))
 			return CSNAPPY_HIP_E_RUNTIME;
 		if (P.cap2) {
 			A.lds0 = P.lds0_2;
-			A.s_entries = P.s_entries_2;
-			A.s_shift = P.s_shift_2;
 			A.dense_cap = P.cap2;
 			A.sample_min = 0;
 			A.only_unparsed = 1;
@@ -3704,8 +3648,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		}
 		if (P.fallback) {
 			A.lds0 = P.g_lds0;
-			A.s_entries = P.g_s_entries;
-			A.s_shift = P.g_s_shift;
+			A.s_entries = P.g_keys;
 			A.only_unparsed = 1;
 			if (!hip_ok(hipLaunchKernel(k2, dim3(nb * fpb), dim3(64), args, P.g_lds_bytes, st),
 				    "launch snappy_parse_fragments_gtab"))
