@@ -814,7 +814,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					epoch = FT::kEpochs;
 				}
 			};
-			uint32_t touch_b = 0;
 
 			uint32_t e_final = 0;
 			bool inside = false;
@@ -875,13 +874,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
 				if (TW)
 					late |= (uint32_t)(p0 + 63 >= kLatePos);
-				/* behind the gather (loads return in order: in front of it, the gather would wait for
-				 * this too): touch the id lines two steps ahead -- the exact cursor is not known yet,
-				 * the lines are -- so that the next place() finds them in the cache (text 10.1 -> 9.8 ms
-				 * per GiB with the input lines touched as well; since the record store moved behind the
-				 * gather the ids alone do as much, 9.00 against 9.05, and none costs 9.14) */
-				if (DENSE)
-					touch_b = ids[min(p0 + 128 + 2 * lane, n - 1)];
+				/* (until round 5 the id lines two steps ahead were touched here, behind the gather: 9.00
+				 * against 9.14 ms per GiB of text in round 3; with a step a fifth shorter the four
+				 * instructions cost more than the touch saves: 9.30 against 9.48.  For small fragments
+				 * only -- pages gain 2 % from it -- the test costs text 1.4 %: not kept either.) */
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
 				if (PROF) {
@@ -1077,7 +1073,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			 * of this step's stores: gfx9 counts loads and stores in one vmcnt, so a wait placed
 			 * behind the stores would also sit out the stores' round trip. */
 			tick(7); /* records built */
-			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid) : "v"(touch_b));
+			asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
 			if (PROF)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			tick(8); /* wait for the next step's bytes (in front of this step's stores) */
