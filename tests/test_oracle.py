@@ -312,6 +312,51 @@ def test_lean_step_model_is_bit_exact(port, urls):
         assert wm.compress_fragment_v5(bytes(pg), 13) == port.compress_fragment(pg, 13)
 
 
+def test_round5_step_model_is_bit_exact(port, urls):
+    """v6 of the model = round 5's step loop: slot sharing known exactly, every lane with a bucket
+    flagged in the steps behind one that may have inserted a position >= the late threshold (moved
+    down here so that whole fragments run "late"), the chain's first stop in lane 0's next-stop
+    entry, the (pz, q1) cursor and the one-compare end of the scan -- held against the oracle."""
+    import wave_model as wm
+    frag = urls[400000:400000 + 32768]
+    for p in (16, 13, 9):
+        st = {}
+        assert wm.compress_fragment_v6(frag, p, stats=st) == port.compress_fragment(frag, p)
+        assert st["steps"] < len(frag) // 8
+    # the end of a full fragment: the steps behind position 0x7fc1 (and a model in which every step is one)
+    for off in (0, 17, 4099):
+        frag = urls[off:off + 32768]
+        assert wm.compress_fragment_v6(frag, 16) == port.compress_fragment(frag, 16)
+        assert wm.compress_fragment_v6(frag[:9000], 16, late_pos=64) == port.compress_fragment(frag[:9000], 16)
+    rng = np.random.default_rng(11)
+    visits = 0
+    for x, p in _fuzz_inputs(8, 260, 5000):
+        x = x[:32768]
+        lm = int(rng.choice([4, 8, 16]))
+        late_pos = int(rng.choice([0x7fc1, 1000, 64]))
+        st = {}
+        assert wm.compress_fragment_v6(x.tobytes(), p, stats=st, lm=lm, late_pos=late_pos) == \
+            port.compress_fragment(x, p), (len(x), p, lm, late_pos)
+        visits += st.get("visits", 0)
+    assert visits > 0
+    # every length around the margin and the first wave steps (the one-compare end of the scan)
+    base = bytes(urls[5000:5400])
+    for n in list(range(0, 100)) + [127, 128, 129, 191, 192, 193]:
+        assert wm.compress_fragment_v6(base[:n], 12) == port.compress_fragment(np.frombuffer(base[:n], np.uint8), 12), n
+    # scan limits that fall on the 64th lane, the lane behind it, the last stride-1 probe
+    big = bytes(urls[20000:21000])
+    for n in range(64, 160):
+        assert wm.compress_fragment_v6(big[:n], 16) == port.compress_fragment(np.frombuffer(big[:n], np.uint8), 16), n
+    # runs (one slot on every lane), incompressible data (sparse steps to the end) and heap-like pages
+    noise = np.random.default_rng(5).integers(0, 256, 6000, dtype=np.uint8).tobytes()
+    for blob in (b"\0" * 5000, b"ab" * 3000, b"abcdefgh" * 700 + b"x" + b"abcdefgh" * 50, noise, noise[:1000] + b"q" * 300 + noise[:777]):
+        assert wm.compress_fragment_v6(blob, 14) == port.compress_fragment(np.frombuffer(blob, np.uint8), 14)
+    pages = api.generate_host(2, 0xC5A90004, 0, 32, 4096)
+    for i in range(32):
+        pg = pages[i * 4096:(i + 1) * 4096]
+        assert wm.compress_fragment_v6(bytes(pg), 13) == port.compress_fragment(pg, 13)
+
+
 # ---- batch drivers used by the GPU parity tests and the CPU baseline --------------------------
 def test_batch_drivers_match_single_calls(port, urls):
     b = api.Batch.uniform(len(urls), 65536, device=None)

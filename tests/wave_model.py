@@ -780,3 +780,188 @@ def compress_fragment_v5(F, p, s_entries=None, stats=None, lm=LM):
     if next_emit < n:
         records.append((next_emit, n - next_emit, 0, 0))
     return encode_records(F, records)
+
+
+def compress_fragment_v6(F, p, stats=None, lm=LM, late_pos=0x7fc1):
+    """Round 5's step loop (parse_lean in csnappy_kernels.hip, the placements with their table in
+    LDS), on the scalar side: the lanes that share their SLOT with a lower lane of the step are known
+    exactly (the returning add on the table entry counts them); once a step may have inserted a
+    position >= late_pos every lane with a bucket is flagged instead (an add could carry out of such
+    an entry's half of its dword) -- a flagged lane's visit is exact whatever flagged it; lane 0, which
+    is insert-only, holds the chain's FIRST stop in its next-stop entry (the same search with cl = 0
+    and lim0 probes) and the walk starts at it; the cursor is (pz, q1): pz = the position lane 0 of the
+    next step takes, q1 as in v5, the scan's start pz - q1 + 2 only computed by sparse steps; a dense
+    step ends the fragment's scan exactly when pz + 1 reaches the scan limit."""
+    F = bytes(F)
+    n = len(F)
+    shift = 33 - p
+    pad = F + b"\0" * 64
+    rd32 = lambda i: struct.unpack_from("<I", pad, i)[0]
+    records = []
+    next_emit = 0
+
+    def lcp(a, b, start, limit):
+        k = start
+        while k < limit and F[a + k] == F[b + k]:
+            k += 1
+        return k
+
+    if n > MARGIN:
+        tab = [0] * (1 << (p - 1))
+        ip_limit = n - MARGIN
+        pz, q1 = 0, 1
+        fin = False
+        late = False
+        guard = 0
+        while not fin:
+            guard += 1
+            assert guard <= n, "the cursor stopped moving"
+            if stats is not None:
+                stats["steps"] = stats.get("steps", 0) + 1
+            sparse = q1 > 32
+            p0 = pz
+            s = pz - q1 + 2
+            pos, valid = [0] * WAVE, [False] * WAVE
+            for l in range(WAVE):
+                if sparse:
+                    pos[l] = scan_pos(s, q1 - 1 + l)
+                    valid[l] = scan_pos(s, q1 + l) <= ip_limit
+                else:
+                    pos[l] = p0 + l
+                    valid[l] = pos[l] < ip_limit
+                if not valid[l]:
+                    pos[l] = 0
+            h = [((rd32(pos[l]) * KMUL) & 0xFFFFFFFF) >> shift for l in range(WAVE)]
+            tabbed = valid[:]
+            cand = [tab[h[l]] if tabbed[l] else 0 for l in range(WAVE)]
+            seen = set()
+            flagged = [False] * WAVE  # the lanes that share their slot with a lower lane (late: every lane with a bucket)
+            for l in range(WAVE):
+                if tabbed[l]:
+                    if (h[l] in seen or late) and l != 0:
+                        flagged[l] = True
+                    seen.add(h[l])
+            if sparse:
+                v = next((l for l in range(WAVE) if not valid[l]), 64)
+                c1 = next((l for l in range(WAVE) if flagged[l]), 64)
+                ul = min(c1, v)
+                mlen = [lcp(cand[l], pos[l], 0, lm) if l < ul and tabbed[l] else 0 for l in range(WAVE)]
+                m = next((l for l in range(ul) if mlen[l] >= 4), None)
+                if m is None:
+                    e_final = ul - 1
+                    if ul == v and v < 64:
+                        fin = True
+                    else:
+                        q1 += ul
+                        pz += ul
+                else:
+                    e_final = m
+                    base, cnd, L = pos[m], cand[m], mlen[m]
+                    if L == lm and base + L < n:
+                        L = lcp(cnd, base, lm, n - base)
+                    records.append((next_emit, base - next_emit, base - cnd, L))
+                    ip = base + L
+                    next_emit = ip
+                    if ip >= ip_limit:
+                        fin = True
+                    pz, q1 = ip - 1, 0
+                if 0 <= e_final < WAVE and pos[e_final] >= late_pos:
+                    late = True
+                for l in range(WAVE):
+                    if l <= e_final and tabbed[l]:
+                        tab[h[l]] = pos[l]
+                continue
+
+            # ---- dense step ----
+            ulim = min(64, ip_limit - p0)
+            if p0 + 63 >= late_pos:
+                late = True  # (for the steps behind this one)
+            mlen = [lcp(cand[l], pos[l], 0, lm) if tabbed[l] and l != 0 else 0 for l in range(WAVE)]
+            stopm = [mlen[l] >= 4 or flagged[l] for l in range(WAVE)]
+            special = [(mlen[l] == lm and p0 + l + lm < n) or flagged[l] for l in range(WAVE)]
+            cl = [l + mlen[l] for l in range(WAVE)]
+
+            def next_code(cc):
+                if cc >= ulim:
+                    return 64
+                j = next((x for x in range(cc, 64) if stopm[x]), None)
+                if j is None or j - cc > 32:
+                    return 65
+                return j | (128 if special[j] else 0)
+
+            lim0 = 33 - q1
+
+            def lane_code(l):
+                # lane 0: the first stop among lanes 1 .. lim0 (cl = 0, lim0 probes); the others as in v5
+                if cl[l] >= ulim:
+                    return 64
+                j = next((x for x in range(cl[l], 64) if stopm[x]), None)
+                if j is None or j - cl[l] > (lim0 if l == 0 else 32):
+                    return 65
+                return j | (128 if special[j] else 0)
+
+            nx = [lane_code(l) for l in range(WAVE)]
+            taken = []
+            t = nx[0]  # (the kernel's walk starts AT lane 0 and clears its mark afterwards)
+            while True:
+                while t < 64:
+                    taken.append(t)
+                    t = nx[t]
+                if t < 128:
+                    break
+                i = t & 63
+                L = mlen[i]
+                if flagged[i]:
+                    if stats is not None:
+                        stats["visits"] = stats.get("visits", 0) + 1
+                    # highest lower lane with the same slot that this step inserts (not strictly inside a taken copy)
+                    def inside(x):
+                        below = [y for y in taken if y < x]
+                        return bool(below) and x + 1 < cl[below[-1]]
+                    same = [x for x in range(i) if tabbed[x] and h[x] == h[i] and not inside(x)]
+                    if same:
+                        j = same[-1]
+                        L = lcp(pos[j], pos[i], 0, lm)
+                        cand[i] = p0 + j
+                        if stats is not None:
+                            stats["fwd"] = stats.get("fwd", 0) + 1
+                    if L < 4:
+                        lim_cur = cl[taken[-1]] + 32 if taken else lim0
+                        i2 = next((x for x in range(i + 1, 64) if stopm[x]), 64)
+                        t = 65 if (i2 > lim_cur or i2 > 63) else i2 | (128 if special[i2] else 0)
+                        continue
+                if L == lm and p0 + i + lm < n:
+                    L = lcp(cand[i], p0 + i, lm, n - (p0 + i))
+                mlen[i], cl[i] = L, i + L
+                taken.append(i)
+                t = next_code(i + L)
+            emit0 = next_emit
+            any_ = bool(taken)
+            last = taken[-1] if any_ else 0
+            c = cl[last]
+            ip = p0 + c
+            end_a = t == 64
+            lim = c + 32 if any_ else lim0
+            e = min(lim, ulim - 1)
+            e_final = last if end_a else e
+            if any_:
+                next_emit = ip
+            q1 = 0 if end_a else (e + 1 - c if any_ else q1 + e)
+            pz = p0 + (c - 1 if end_a else e)
+            fin = pz + 1 >= ip_limit
+            prev_end = None
+            for l in taken:
+                records.append((emit0 if prev_end is None else p0 + prev_end, None, p0 + l - cand[l], mlen[l], p0 + l))
+                prev_end = cl[l]
+            # commit: lanes up to e_final that are not strictly inside a taken copy; the last lane of a slot wins
+            def inside_final(x):
+                below = [y for y in taken if y < x]
+                return bool(below) and x + 1 < cl[below[-1]]
+            for l in range(WAVE):
+                if l <= e_final and tabbed[l] and not inside_final(l):
+                    tab[h[l]] = pos[l]
+        # (records of dense steps carry (lit_start, -, offset, length, base): bring them to the common form)
+        records = [(r[0], r[4] - r[0], r[2], r[3]) if len(r) == 5 else r for r in records]
+    if next_emit < n:
+        records.append((next_emit, n - next_emit, 0, 0))
+    return encode_records(F, records)
