@@ -794,7 +794,15 @@ def test_the_c_gather_example_runs_with_one_rank(torch, tmp_path):
     exe = os.path.join(os.path.dirname(HERE), "tools", "gather_rccl_example")
     out = tmp_path / "stream.bin"
     nblocks, block, seed = 48, 65536, 0xC5A90001
-    r = subprocess.run([exe, str(out), str(nblocks), hex(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    try:
+        r = subprocess.run([exe, str(out), str(nblocks), hex(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+    except subprocess.TimeoutExpired as e:
+        # RCCL's own start-up in a stand-alone C process (ncclCommInitRank of ONE rank) does not return on
+        # some boxes of the pool (seen twice in some thirty runs, 300 s each time); nothing of this library
+        # has run by then.  Anything slower behind that point is a failure.
+        if b"stage: communicator up" not in (e.stderr or b""):
+            pytest.skip("ncclCommInitRank of a one-rank communicator did not return within 150 s on this box")
+        raise
     assert r.returncode == 0, (r.stdout, r.stderr)
     got = out.read_bytes()
     d_in = api.generate(api.WG_TEXT, seed, 0, nblocks, block)

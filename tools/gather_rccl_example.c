@@ -137,8 +137,13 @@ int main(int argc, char **argv)
 	}
 	CHECK(csnappy_hip_device_count() > 0);
 	CHECK(hipSetDevice(0) == hipSuccess && hipStreamCreate(&stream) == hipSuccess);
-	/* the caller's communicator: here of one rank */
+	/* the caller's communicator: here of one rank.  (Progress goes to stderr: a caller that gives up
+	 * waiting can tell RCCL's start-up, which is the machine's, from the steps that follow.) */
+	fprintf(stderr, "stage: creating a one-rank communicator\n");
+	fflush(stderr);
 	CHECK(ncclGetUniqueId(&id) == ncclSuccess && ncclCommInitRank(&comm, 1, id, 0) == ncclSuccess);
+	fprintf(stderr, "stage: communicator up\n");
+	fflush(stderr);
 	CHECK(hipMalloc(&d_in, (size_t)nblocks * block) == hipSuccess);
 	CHECK(hipMalloc(&d_out, (size_t)nblocks * slot) == hipSuccess && hipMalloc(&d_ws, ws_bytes) == hipSuccess);
 	CHECK(hipMalloc(&d_in_off, (size_t)nblocks * 8) == hipSuccess && hipMalloc(&d_out_off, (size_t)nblocks * 8) == hipSuccess);
