@@ -964,15 +964,20 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 						 * bytes -- else the table value it already compared with. */
 						const uint32_t slot_i = rdlane(slot, i);
 						uint64_t same = ballot64(slot == slot_i) & tmask & ((1ull << i) - 1);
-						/* (highest first; a lane strictly inside the nearest taken copy below it was never
-						 * inserted: the next lower one then.  On the scalar unit: a ds_bpermute of the
-						 * copies' ends to every lane did this until round 5, one LDS round trip a visit) */
-						while (same) {
-							const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
-							const uint64_t kb = taken & ((1ull << j) - 1);
-							if (!kb || j + 1 >= rdlane(cl, 63u - (uint32_t)__builtin_clzll(kb)))
-								break;
-							same &= ~(1ull << j);
+						/* A lane strictly inside the nearest taken copy below it was never inserted.  The
+						 * highest of `same` is tested on the scalar unit (it nearly always was inserted:
+						 * no LDS round trip then); if it was not, all of them are settled at once with a
+						 * ds_bpermute of the copies' ends (runs put the slot on every lane below: one by
+						 * one on the scalar unit they cost pages a quarter of their speed) */
+						if (same && taken) {
+							const uint32_t jh = 63u - (uint32_t)__builtin_clzll(same);
+							const uint64_t kb = taken & ((1ull << jh) - 1);
+							if (kb && jh + 1 < rdlane(cl, 63u - (uint32_t)__builtin_clzll(kb))) {
+								const uint64_t below = taken & lt_mask;
+								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+								same &= ~ballot64(below != 0 && lane + 1 < cprev);
+							}
 						}
 						if (same) {
 							const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
