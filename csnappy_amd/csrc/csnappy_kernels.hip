@@ -1558,7 +1558,11 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	return total;
 }
 
-constexpr uint32_t kEmitWaves = 4;
+/* waves per workgroup of the emit kernels.  One since round 5: every wave of a fragment's workgroup
+ * takes a run of consecutive chunks and keeps its own staging, so the waves never needed each other --
+ * and one wave per workgroup leaves the scheduler the finest grain (1 / 2 / 3 / 4 / 8 waves: 1.15 / 1.18 /
+ * 1.24 / 1.30 / 1.68 ms per GiB of text, pages 1.23 / 1.28 / 1.35 / 1.52 / 1.78, G_low 0.22 / 0.23 / 0.27 / 0.31) */
+constexpr uint32_t kEmitWaves = 1;
 constexpr uint32_t kMaxChunks = (kFragment / 4 + 8 + 63) / 64; /* 64-record chunks of one fragment (<= 8193 records): their totals fit the first 1 KiB of its id region */
 static_assert(kMaxChunks <= 254, "chunk offsets + two words live in the smallest id region (1 KiB)");
 
