@@ -273,7 +273,8 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
 constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging (but see kMediumLiteral) */
 constexpr uint32_t kMediumLiteral = 256; /* longest literal staged by the wave for its lane */
-constexpr uint32_t kStageBytes = 16 + 64 * kBigRecord + 16 + 32; /* LDS output staging of one emit wave */
+constexpr uint32_t kStageCap = 64 * kBigRecord; /* bytes an emit wave stages before it drains: a chunk of small records fits (4 / 8 KiB: +-1 %, round 5) */
+constexpr uint32_t kStageBytes = 16 + kStageCap + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
 constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
@@ -1356,7 +1357,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	/* A record with a literal of 32..kMediumLiteral bytes (text: one in 150, but it used to split
 	 * its chunk in two stagings and two drains) is staged like a small one when the whole chunk
 	 * fits the staging: its header and tags by its lane, its literal's bytes by the wave. */
-	const bool medium = live && !small && total <= 64 * kBigRecord && lit_len <= kMediumLiteral && cp.bytes <= 16;
+	const bool medium = live && !small && total <= kStageCap && lit_len <= kMediumLiteral && cp.bytes <= 16;
 	const uint64_t medmask = ballot64(medium);
 	uint64_t bigmask = ballot64(live && !small && !medium);
 	const uint32_t lw[8] = { in.la.x, in.la.y, in.la.z, in.la.w, in.lb.x, in.lb.y, in.lb.z, in.lb.w };
@@ -1365,7 +1366,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	asm volatile("" : : "v"(excl), "v"(lw[0]), "v"(lw[7]));
 #endif
 	EMIT_TICK(0); /* decode, offsets (and the wait for the chunk's own loads) */
-	if (fill && fill + total > 64 * kBigRecord)
+	if (fill && fill + total > kStageCap)
 		drain(); /* (a chunk with a big record may exceed the staging by itself: its runs do not) */
 	while (nev) {
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
