@@ -1673,7 +1673,8 @@ DEVINL bool emit_frag_setup(const CompressArgs &A, EmitFrag &F, bool after_bases
 	return true;
 }
 
-extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_sizes(CompressArgs A)
+constexpr uint32_t kSizesWaves = 4; /* waves per workgroup of snappy_emit_sizes (they meet at one barrier) */
+extern "C" __global__ void __launch_bounds__(64 * kSizesWaves) snappy_emit_sizes(CompressArgs A)
 {
 	__shared__ uint32_t chunk_tot[kMaxChunks];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1681,16 +1682,16 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves) snappy_emit_sizes(
 	if (!emit_frag_setup(A, F, false))
 		return;
 	/* encoded bytes of every 64-record chunk (four chunks' records in flight) */
-	for (uint32_t c0 = wv; c0 < F.nchunks; c0 += 4 * kEmitWaves) {
+	for (uint32_t c0 = wv; c0 < F.nchunks; c0 += 4 * kSizesWaves) {
 		uint2 rr[4];
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j) {
-			const uint32_t r = (c0 + j * kEmitWaves) * 64 + lane;
+			const uint32_t r = (c0 + j * kSizesWaves) * 64 + lane;
 			rr[j] = r < F.cnt ? F.R[r] : make_uint2(0, 0);
 		}
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j) {
-			const uint32_t ch = c0 + j * kEmitWaves;
+			const uint32_t ch = c0 + j * kSizesWaves;
 			if (ch < F.nchunks) {
 				const RecFields f = decode_record(rr[j], ch * 64 + lane < F.cnt);
 				uint32_t total;
@@ -3667,7 +3668,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 			hipLaunchKernelGGL(snappy_emit_pages, dim3((nb + kEmitWaves - 1) / kEmitWaves), dim3(64 * kEmitWaves), 0,
 					   st, A);
 		else {
-			hipLaunchKernelGGL(snappy_emit_sizes, dim3(nb * fpb), dim3(64 * kEmitWaves), 0, st, A);
+			hipLaunchKernelGGL(snappy_emit_sizes, dim3(nb * fpb), dim3(64 * kSizesWaves), 0, st, A);
 			hipLaunchKernelGGL(snappy_emit_bases, dim3(nb), dim3(64), 0, st, A);
 			hipLaunchKernelGGL(snappy_emit_blocks, dim3(nb * fpb), dim3(64 * kEmitWaves), 0, st, A);
 		}
