@@ -277,10 +277,11 @@ constexpr uint32_t kStageCap = 64 * kBigRecord; /* bytes an emit wave stages bef
 constexpr uint32_t kStageBytes = 16 + kStageCap + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
-constexpr uint32_t kNoBucket = 0xffffu;      /* dense id of a position whose slot nobody else hits */
+constexpr uint32_t kNoBucket = 0;            /* dense id of a position whose slot nobody else hits */
+constexpr uint32_t kFirstBucket = 2;         /* ... and of the first bucket: entries 0 and 1 of the dense table are one dummy
+                                              * dword that the lanes without a bucket may read, bump and overwrite at will */
 constexpr uint32_t kSpillFilterEntries = 128; /* the spilled lanes' conflict filter (u32 tags) ... */
 constexpr uint32_t kSpillFilterSlots = kSpillFilterEntries * 2; /* ... takes the place of this many table entries */
-constexpr uint32_t kLatePos = 0x7fc1;   /* table entries of positions from here on are within 63 of 0xffff (parse_lean, TW) */
 
 enum { TAB_LDS_HASH = 0, TAB_LDS_DENSE = 1, TAB_GLOBAL = 2 };
 
@@ -385,8 +386,10 @@ DEVINL bool frag_setup(const CompressArgs &A, Frag &F, bool gtab)
 
 /* The dense placement's prologue (see the header comment above): numbers the hash slots that two or
  * more positions of the fragment hit and writes every position's dense bucket id to the fragment's
- * workspace region.  Returns the bucket count, or kNoRecords when the fragment was handed to a
- * later launch (too many buckets, or repetitive: the global-table launch is faster for it). */
+ * workspace region (0 = no bucket, the buckets count from kFirstBucket).  Returns the number of ids
+ * in use -- buckets + kFirstBucket, the table entries the fragment needs --, or kNoRecords when the
+ * fragment was handed to a later launch (too many buckets, or repetitive: the global-table launch is
+ * faster for it). */
 DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -502,7 +505,8 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 			mine += (uint32_t)__builtin_popcount(seen2[w]);
 	}
 	uint32_t nb;
-	uint32_t run = wave_excl_scan(mine, lane, &nb);
+	uint32_t run = wave_excl_scan(mine, lane, &nb) + kFirstBucket;
+	nb += kFirstBucket; /* ids in use */
 	/* (a fragment with more buckets than the LDS table gives the table's last kSpillFilterSlots
 	 * entries to its spilled lanes' filter, see parse_lean) */
 	if (nb > A.dense_cap && nb > A.dense_cap + A.spill_cap - (A.spill_cap ? kSpillFilterSlots : 0u)) {
@@ -551,7 +555,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	return nb;
 }
 
-template <int TAB, bool SPILL, bool PROF = false>
+template <int TAB, bool SPILL, bool PROF = false, bool ORD = true>
 DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 {
 	/* PROF: s_memtime phase counters (debug kernels only; tools/phase_lean.py) */
@@ -596,12 +600,19 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	 * thirty instructions of tag arithmetic per step, false alarms, 1 KiB of LDS) and the commit's
 	 * dedupe rounds are gone from those placements; the few lanes of a SPILL fragment whose bucket lives
 	 * in HBM keep one small filter among themselves, carved out of the table's tail.  The global table
-	 * keeps both filters (a returning atomic through memory would cost a round trip).
-	 * The add must not carry from the low half of a dword into the high one: entries are position |
-	 * check bit << 15 with positions < 32 754, at most 63 lower lanes -- a carry needs an entry of a
-	 * position >= kLatePos, and the steps behind one that may have inserted such a position (`late`: the
-	 * last one or two of a full fragment) flag every lane instead; a flagged lane's visit is exact
-	 * whatever flagged it.  Lanes without a bucket add 0 to entry 0 (no exec juggling). */
+	 * finds sharing with one returning exchange on a keyed array (see there).
+	 * The add may carry from the low half of a dword into the high one (an entry within 63 of 0xffff).
+	 * That can only FLAG a lane of the high half that has no sharer -- its half comes back one too high --
+	 * never hide one (a half's own count is <= 63, the carry <= 1), and a flagged lane's visit is exact
+	 * whatever flagged it.  The commit undoes the adds by SUBTRACTING them again (round 6; commutative,
+	 * exact modulo 2^32 whatever carried), so no entry is left changed; until then the lanes that were
+	 * not inserted stored their entry back, a carry into a half nobody held was never undone, and the
+	 * last steps of a full fragment had to flag every lane instead (`late`).
+	 * Lanes without a bucket (id 0) read, bump and restore the dummy dword, entries 0 and 1.
+	 * ORD = false (the device's LDS does not keep that order, or CSNAPPY_HIP_NO_LDS_ORDER=1): no add,
+	 * no exchange; every lane with a bucket is flagged, so every stop of the chain is resolved from
+	 * the lower lanes' registers, and the commit lets one lane per slot store (its dedupe rounds).
+	 * Exact on any hardware, several times slower. */
 	constexpr bool TW = !GTAB;
 	constexpr bool FILT = GTAB || SPILL;
 	/* TW + SPILL: the last kSpillFilterSlots entries of the LDS table are the spilled lanes' filter */
@@ -678,7 +689,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t pz = 0, q1 = 1;
 		uint32_t epoch = FT::kEpochs;
 		bool fin = false;
-		uint32_t late = 0; /* TW: an earlier step inserted a position >= kLatePos (see above) */
 
 		/* the lanes' 16 bytes and bucket ids are fetched one step ahead, as soon as the next
 		 * step's cursor is known */
@@ -753,7 +763,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				 * (Until round 5: two atomic minima, two reads and thirty instructions of tag
 				 * arithmetic.)  The tag's epoch field is epoch - 1: never that of the ~0 fill. */
 				key = slot & smask;
-				if (tabbed)
+				if (ORD && tabbed)
 					xold = atomicExch(&S[key], ((epoch - 1) << (7 + 15)) | (slot << 7) | lane);
 				const bool written = tabbed && ((occ[slot >> 5] >> (slot & 31)) & 1u);
 				cand = gtab[written ? slot : 0u];
@@ -762,15 +772,16 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				raw16 = tab[in_lds ? slot : 0u];
 				if (!CHK0_INIT)
 					raw16 = in_lds ? raw16 : 0u;
-				const bool adds = in_lds && late == 0;
-				bumped = atomicAdd(&tab32[adds ? slot >> 1 : 0u], adds ? 1u << ((slot & 1u) << 4) : 0u);
+				if (ORD)
+					bumped = atomicAdd(&tab32[in_lds ? slot >> 1 : 0u], in_lds ? 1u << ((slot & 1u) << 4) : 0u);
 				cand = raw16;
 			}
 			if (SPILL && ballot64(spilled)) {
 				/* the lanes whose bucket lies in HBM: one filter among themselves (a lane it does not
 				 * settle is flagged to be safe; they are few, so that is rare) */
 				key = (slot - dense_cap) & smask;
-				atomicMin(&S[key], FT::tag(epoch, slot, lane, spilled));
+				if (ORD)
+					atomicMin(&S[key], FT::tag(epoch, slot, lane, spilled));
 				const uint32_t g = spill[spilled ? slot - dense_cap : 0u];
 				cand = spilled ? g : cand;
 			}
@@ -788,19 +799,21 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			 * issue in either kind of step: the kinds are told apart ONCE per step) */
 			auto step_flags = [&]() {
 				tmask = ballot64(tabbed);
-				if (!TW) {
+				if (!ORD) {
+					cmask = tmask & ~1ull; /* (lane 0 has no lower lane) */
+				} else if (!TW) {
 					cmask = ballot64((xold >> (7 + 15)) == epoch - 1) & tmask;
 				} else {
-					/* my half of the dword as the add found it: the entry + the lower lanes of my slot */
+					/* my half of the dword as the add found it: the entry + the lower lanes of my slot
+					 * (+ 1, rarely, for a carry out of the low half: a false alarm) */
 					const uint32_t seen = (bumped >> ((slot & 1u) << 4)) & 0xffffu;
-					const uint64_t shared = ballot64(seen != raw16) & tmask;
-					cmask = late ? tmask & ~1ull : shared;
+					cmask = ballot64(seen != raw16) & tmask;
 					if (SPILL && ballot64(spilled)) {
 						const uint32_t fe1 = S[key];
 						cmask = (cmask & ~ballot64(spilled)) | ballot64(spilled & FT::flags(fe1, slot, lane));
 					}
 				}
-				if (FILT && --epoch == 0) {
+				if (ORD && FILT && --epoch == 0) {
 					/* the tags' epoch field is about to wrap: start over with empty filters */
 					wave_lds_fence();
 					uint4 *s4 = reinterpret_cast<uint4 *>(S);
@@ -858,8 +871,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					pz = ip - 1;
 					q1 = 0;
 				}
-				if (TW)
-					late |= (uint32_t)(rdlane(pos_c, e_final) >= kLatePos);
 				place();
 			} else {
 				/* ---- dense step: lane L holds position p0 + L; lane 0 is insert-only ---- */
@@ -868,8 +879,6 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				step_flags();
 				tick(2); /* filters + table */
 				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
-				if (TW)
-					late |= (uint32_t)(p0 + 63 >= kLatePos);
 				/* (until round 5 the id lines two steps ahead were touched here, behind the gather: 9.00
 				 * against 9.14 ms per GiB of text in round 3; with a step a fifth shorter the four
 				 * instructions cost more than the touch saves: 9.30 against 9.48.  For small fragments
@@ -934,23 +943,20 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				tick(4); /* match lengths, next-stop table */
 				/* plain matches: hop from match to match (unrolling this loop four times was
 				 * measured in round 3: no gain) */
-	/* (one block, the mark in FRONT of the v_readlane: the mark, the compare, the move and the branch
-	 * are then the four wait states the next v_readlane's lane select needs, and the mark is the one
-	 * the first v_readlane needs behind the vector instruction that wrote nx -- written apart, the
-	 * compiler pays a wait state of its own inside the loop) */
-#define CSNAPPY_HOP()                                                                              \
-	{                                                                                          \
-		uint32_t tn;                                                                       \
-		asm volatile("s_bitset1_b64 %0, %2\n\tv_readlane_b32 %1, %3, %2"                   \
-			     : "+s"(taken), "=&s"(tn) : "s"(t), "v"(nx)); /* taken |= 1ull << t; tn = nx[t] */ \
-		t = tn;                                                                            \
-	}
-				/* (the walk of a step without special lanes -- four steps in five -- is this loop alone:
-				 * written as the head of the loop below it dragged that loop's carried copies of the
-				 * lanes' match length, end and candidate into every step) */
-				do {
-					CSNAPPY_HOP();
-				} while (t < 64);
+	/* The hops of the walk, t = nx[t] until t >= 64, every lane passed marked in `taken`: the whole loop
+	 * is one asm block, so that the wait states are spelled out here and do not hang on what the
+	 * compiler happens to put between two of its iterations (its hazard recogniser does not look
+	 * inside inline asm).  A v_readlane whose lane select was written by the vector unit -- the
+	 * previous hop's v_readlane -- needs four wait states: s_nop 0, s_cmp, s_cbranch and the next
+	 * hop's mark are those four; the mark in FRONT of the v_readlane is also the one wait state the
+	 * first v_readlane needs behind the vector instruction that wrote nx.  t on entry comes from the
+	 * scalar unit (a constant, or scalar arithmetic), which needs none.  Five instructions a hop. */
+#define CSNAPPY_HOPS()                                                                             \
+	asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\tv_readlane_b32 %1, %2, %1\n\ts_nop 0\n\t"           \
+		     "s_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b"                                     \
+		     : "+s"(taken), "+s"(t) : "v"(nx) : "scc") /* do { taken |= 1ull << t; t = nx[t]; } while (t < 64) */
+				/* (the walk of a step without special lanes -- four steps in five -- is this loop alone) */
+				CSNAPPY_HOPS();
 				taken &= ~1ull; /* (lane 0 is where the walk starts, not a match) */
 				while (__builtin_expect(t >= 128, 0)) {
 					const uint32_t i = t & 63u;
@@ -997,8 +1003,8 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 							const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
 							const uint32_t i2 = m ? first_lane(m) : 64u;
 							t = (i2 > lim_cur || i2 > 63) ? 65u : i2 | (((uint32_t)(special >> (i2 & 63u)) & 1u) << 7);
-							while (t < 64)
-								CSNAPPY_HOP();
+							if (t < 64)
+								CSNAPPY_HOPS();
 							continue;
 						}
 					}
@@ -1012,10 +1018,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					}
 					taken |= 1ull << i;
 					t = scalar_next(i + L);
-					while (t < 64)
-						CSNAPPY_HOP();
+					if (t < 64)
+						CSNAPPY_HOPS();
 				}
-#undef CSNAPPY_HOP
+#undef CSNAPPY_HOPS
 				/* ---- where the chain left the step (selects, no branches: this is scalar code) ----
 				 * t == 64: the last copy ends at or behind the usable lanes: re-match probe next
 				 * (:585-594).  t == 65: the current window (the 33 probes behind the last copy, or what
@@ -1093,7 +1099,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				/* of several committed lanes with one slot only the last may write */
 				const uint64_t cm = ballot64(commit);
 				uint64_t fl = cmask & cm;
-				if (TW) /* (the LDS keeps the highest lane of a slot by itself; only stores to HBM need this) */
+				if (TW && ORD) /* (the LDS keeps the highest lane of a slot by itself; only stores to HBM need this) */
 					fl = SPILL ? fl & ballot64(spilled) : 0;
 				if (fl) {
 					/* one round per SLOT that several committed lanes share, highest lane first: it
@@ -1116,13 +1122,13 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					atomicOr(&occ[slot >> 5], 1u << (slot & 31));
 				}
 			} else {
-				/* TW: the lanes that are not inserted put their entry back (the add changed it); then the
-				 * inserted ones write theirs -- a store of its own, so that it comes after every
-				 * restore of the same slot, and of several inserted lanes with one slot the LDS keeps
+				/* TW: the adds are taken back (a subtraction each: whatever carried is undone with it);
+				 * then the inserted lanes write their entries -- of several with one slot the LDS keeps
 				 * the highest (ascending lane order) */
-				if (in_lds && !commit)
-					tab[slot] = (uint16_t)raw16;
-				wave_lds_fence();
+				if (ORD) {
+					(void)atomicSub(&tab32[in_lds ? slot >> 1 : 0u], in_lds ? 1u << ((slot & 1u) << 4) : 0u);
+					wave_lds_fence();
+				}
 				if (in_lds && commit)
 					tab[slot] = (uint16_t)mine16;
 			}
@@ -1193,6 +1199,38 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab(
 	if (!frag_setup(A, F, true))
 		return;
 	parse_lean<TAB_GLOBAL, false>(A, F);
+}
+
+/* The same three for a device whose LDS does not serve one instruction's lanes in ascending order (or
+ * CSNAPPY_HIP_NO_LDS_ORDER=1): parse_lean<.., ORD = false>, exact on any hardware, several times slower. */
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_dense_lean_unordered(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, false))
+		return;
+	const uint32_t nb = dense_prologue(A, F);
+	if (nb == kNoRecords)
+		return;
+	if (nb > A.dense_cap)
+		parse_lean<TAB_LDS_DENSE, true, false, false>(A, F);
+	else
+		parse_lean<TAB_LDS_DENSE, false, false, false>(A, F);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_hash_lean_unordered(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, false))
+		return;
+	parse_lean<TAB_LDS_HASH, false, false, false>(A, F);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_unordered(CompressArgs A)
+{
+	Frag F;
+	if (!frag_setup(A, F, true))
+		return;
+	parse_lean<TAB_GLOBAL, false, false, false>(A, F);
 }
 
 /* debug: the dense kernel with s_memtime phase counters (csnappy_hip_debug_set_profile_buffer) */
@@ -3038,42 +3076,87 @@ extern "C" __global__ void __launch_bounds__(64) snappy_crc32c_blocks(CrcArgs A)
 }
 
 /* ==========================================================================================
- * The LDS property the parsers with their table in LDS rely on (parse_lean, "TW"): the lanes of ONE
- * LDS instruction that hit one address are served in ascending lane order -- a returning add hands
- * every lane the sum of the LOWER lanes' addends, and of several stores the highest lane's data
- * stays.  The ISA manual does not promise it; tools/ubench/lds_order.hip measured it on gfx950
- * (2.5 M lanes in shared slots, no exception), and this probe repeats the measurement on the device
- * in hand before the first parser launch of a process: a device that answers differently makes
- * every compress call fail instead of producing a stream that is not the reference's.
+ * The LDS property the ORD parsers rely on (parse_lean, "TW", and the global-table kernel's exchange):
+ * the lanes of ONE LDS instruction that hit one address are served in ascending lane order -- a
+ * returning add hands every lane the sum of the LOWER lanes' addends, a returning exchange the value
+ * the nearest lower lane put there, and of several stores the highest lane's data stays.  The ISA
+ * manual does not promise it; tools/ubench/lds_order.hip measured it on gfx950 (2.5 M lanes in
+ * shared slots, no exception), and this probe repeats the measurement on the device in hand before
+ * the first parser launch of a process, twice: on an idle device (512 waves), and with the parser's
+ * own footprint -- 10 KiB of LDS per workgroup, so sixteen workgroups per CU contend for the LDS,
+ * every CU full -- with the parser's own instructions: ds_read_u16, a returning add on a 16-bit
+ * half of a dword (other lanes on the other half, carries), its subtraction, ds_write_b16 under a
+ * partial exec mask, and ds_wrxchg_rtn on a keyed array; the addresses are drawn like a step's
+ * slots (runs: one slot on most lanes; text: a pair now and then; 2-byte strides over the banks).
+ * A device that answers differently gets the ORD = false kernels: exact without the property.
  * ======================================================================================== */
-extern "C" __global__ void __launch_bounds__(64) snappy_lds_order_probe(uint32_t *bad)
+constexpr uint32_t kProbeEntries = 5120; /* u16 entries: the dense parser's 10 KiB */
+constexpr uint32_t kProbeKeys = 256;     /* the exchange array: the table's last 1 KiB */
+
+extern "C" __global__ void __launch_bounds__(64) snappy_lds_order_probe(uint32_t *bad, uint32_t rounds)
 {
-	__shared__ uint32_t cnt[64];
-	__shared__ uint16_t win[128];
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+	uint32_t *tab32 = reinterpret_cast<uint32_t *>(smem);
+	constexpr uint32_t kSlots = kProbeEntries - 2 * kProbeKeys;
+	uint32_t *keyed = reinterpret_cast<uint32_t *>(smem + 2 * kSlots);
 	const uint32_t lane = threadIdx.x;
 	uint32_t x = (blockIdx.x * 64 + lane) * 0x9E3779B9u + 0x7f4a7c15u, wrong = 0;
-	for (uint32_t round = 0; round < 32; ++round) {
-		cnt[lane] = 0;
-		win[lane] = 0xffff;
-		win[64 + lane] = 0xffff;
-		wave_lds_fence();
+	auto rnd = [&]() {
 		x ^= x << 13;
 		x ^= x >> 17;
 		x ^= x << 5;
+		return x;
+	};
+	for (uint32_t k = lane; k < kSlots / 2; k += 64)
+		tab32[k] = rnd() | ((k & 7u) == 0 ? 0xffc0ffc0u : 0u); /* (some halves within 63 of 0xffff: carries) */
+	for (uint32_t k = lane; k < kProbeKeys; k += 64)
+		keyed[k] = ~0u;
+	wave_lds_fence();
+	for (uint32_t round = 0; round < rounds; ++round) {
 		/* few slots (runs put one slot on most lanes) up to many (text: a pair now and then) */
-		const uint32_t range = 1u + ((blockIdx.x + round) % 7u) * ((blockIdx.x + round) % 7u) * 2u;
-		const uint32_t slot = ((x >> 8) * range) >> 24; /* < range <= 73 */
-		const uint32_t got = atomicAdd(&cnt[slot >> 1], 1u << ((slot & 1u) << 4));
-		win[slot] = (uint16_t)lane;
+		const uint32_t sel = (blockIdx.x + round) % 7u;
+		const uint32_t range = 1u + sel * sel * sel * 2u; /* 1 .. 433 */
+		const uint32_t base = rdlane(rnd(), 0) % (kSlots - 512);
+		const uint32_t slot = base + (((rnd() >> 8) * range) >> 24);
+		const bool inserted = (rnd() >> 9) & 1u; /* (the commit's exec mask) */
+		const uint32_t mine = 0x8000u | (round << 6 & 0x7fc0u) | lane;
+		const uint32_t one = 1u << ((slot & 1u) << 4);
+		const uint32_t orig32 = tab32[slot >> 1];
+		const uint32_t orig16 = tab[slot];
 		wave_lds_fence();
-		uint32_t lower = 0, highest = lane;
+		const uint32_t got = atomicAdd(&tab32[slot >> 1], one);
+		const uint32_t xgot = atomicExch(&keyed[slot & (kProbeKeys - 1)], (round << 16) | (slot << 6 & 0xffc0u) | lane);
+		wave_lds_fence();
+		(void)atomicSub(&tab32[slot >> 1], one);
+		wave_lds_fence();
+		const uint32_t back32 = tab32[slot >> 1];
+		wave_lds_fence();
+		if (inserted)
+			tab[slot] = (uint16_t)mine;
+		wave_lds_fence();
+		const uint32_t end16 = tab[slot];
+		/* what ascending lane order gives */
+		uint32_t sum = 0, top = ~0u, near = ~0u, nearslot = 0;
 		for (uint32_t j = 0; j < 64; ++j) {
-			const uint32_t sj = rdlane(slot, j);
-			lower += (sj == slot && j < lane) ? 1u : 0u;
-			highest = (sj == slot && j > highest) ? j : highest;
+			const uint32_t sj = rdlane(slot, j), ij = rdlane((uint32_t)inserted, j);
+			if ((sj >> 1) == (slot >> 1) && j < lane)
+				sum += 1u << ((sj & 1u) << 4);
+			if (sj == slot && ij)
+				top = j;
+			if ((sj & (kProbeKeys - 1)) == (slot & (kProbeKeys - 1)) && j < lane) {
+				near = j;
+				nearslot = sj;
+			}
 		}
-		wrong += ((got >> ((slot & 1u) << 4)) & 0xffffu) != lower;
-		wrong += win[slot] != highest;
+		wrong += got != orig32 + sum;
+		wrong += back32 != orig32;
+		wrong += end16 != (top == ~0u ? orig16 : (0x8000u | (round << 6 & 0x7fc0u) | top));
+		/* the exchange: the nearest lower lane's tag of this round, else something older */
+		if (near != ~0u)
+			wrong += xgot != ((round << 16) | (nearslot << 6 & 0xffc0u) | near);
+		else
+			wrong += xgot != ~0u && (xgot >> 16) >= round;
 		wave_lds_fence();
 	}
 	if (wrong)
@@ -3182,6 +3265,12 @@ uint32_t max_fragment(uint32_t max_in_len)
 	return max_in_len < kFragment ? max_in_len : kFragment;
 }
 
+/* dense ids a fragment of <= n bytes can need: a bucket has two or more positions, and the ids count from kFirstBucket */
+uint32_t max_ids(uint32_t n)
+{
+	return (n > 3 ? (n - 3) / 2 : 0) + kFirstBucket;
+}
+
 /* records a fragment of <= n bytes can produce: every record but the last holds a copy of >= 4 bytes */
 uint32_t record_cap(uint32_t n)
 {
@@ -3199,10 +3288,14 @@ uint32_t record_cap(uint32_t n)
  *                                                         below which a fragment takes the global table
  *   CSNAPPY_HIP_SPILL_CAP  0..8192 (multiple of 64)       dense placement: buckets beyond the LDS table
  *                                                         kept in HBM (0: a second launch with a larger
- *                                                         LDS table takes such fragments instead) */
+ *                                                         LDS table takes such fragments instead)
+ *   CSNAPPY_HIP_NO_LDS_ORDER 0..1                         1: the parsers that do not rely on the order in which
+ *                                                         the LDS serves one instruction's lanes (the ones a
+ *                                                         device that fails snappy_lds_order_probe gets) */
 struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
+	uint32_t no_lds_order; /* 1: take the ORD = false parsers whatever the probe says */
 	bool ok;
 };
 
@@ -3221,7 +3314,7 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, true };
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, 0, true };
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -3238,6 +3331,7 @@ Knobs read_knobs()
 	       (k.s_entries & (k.s_entries - 1)) == 0;
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_SAMPLE_MIN", 0, 2048, &k.sample_min);
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_NO_LDS_ORDER", 0, 1, &k.no_lds_order);
 	return k;
 }
 
@@ -3267,11 +3361,11 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	ParsePlan P;
 	memset(&P, 0, sizeof(P));
 	const uint32_t slots = 1u << (p - 1);
-	/* two 128-entry filters: a false alarm only costs a visit of the flagged lane when the chain
-	 * gets there (0.3 visits per step on text), and every KiB of LDS is worth ~4 % (one more
-	 * fragment per CU): 256 -> 128 entries costs 1 % at equal occupancy */
+	/* half the keys of the global-table kernel's exchange array (the LDS placements find slot sharing
+	 * through the table itself and have no such array; only a SPILL fragment's lanes in HBM keep a
+	 * 128-entry filter, carved out of the table's tail) */
 	const uint32_t s_cap = kn.s_entries ? kn.s_entries : 128u;
-	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions */
+	/* a fragment of n bytes has at most (n - 3) / 2 buckets of two or more positions (max_ids) */
 	uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
 	uint32_t dense_scratch = 0;
 	const uint32_t most = ((maxfrag / 2 + 63) & ~63u) + 64;
@@ -3308,7 +3402,7 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		const uint32_t scratch = 10u * (slots >> 5);
 		dense_scratch = scratch;
 		P.lds0 = (2 * cap + 15) & ~15u;
-		P.fallback = (maxfrag > 3 && cap < (maxfrag - 3) / 2) || (kn.sample_min && maxfrag == kFragment);
+		P.fallback = cap < max_ids(maxfrag) || (kn.sample_min && maxfrag == kFragment);
 		P.sample_min = kn.sample_min;
 		/* fragments with more buckets than the first table get a second try with a larger one
 		 * (fewer fragments per CU) before the global table: URL lists sit at 4.5-5.5 k buckets */
@@ -3318,8 +3412,8 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		} else if (maxfrag == kFragment && kn.spill_cap) {
 			/* full fragments: the buckets beyond the LDS table go to HBM in the same launch */
 			P.spill_cap = kn.spill_cap;
-			P.fallback = cap + P.spill_cap - kSpillFilterSlots < (maxfrag - 3) / 2 || kn.sample_min;
-		} else if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < (maxfrag - 3) / 2) {
+			P.fallback = cap + P.spill_cap - kSpillFilterSlots < max_ids(maxfrag) || kn.sample_min;
+		} else if (!kn.dense_cap && cap == kDenseCapDefault && kDenseCap2 < slots && kDenseCap2 < max_ids(maxfrag)) {
 			P.cap2 = kDenseCap2;
 		}
 		if (P.cap2) {
@@ -3362,7 +3456,7 @@ uint32_t tab_stride_for(uint32_t maxfrag, const Knobs &kn)
 {
 	const uint32_t ids = ((maxfrag + 63) & ~63u) * 2;
 	const uint32_t cap = kn.dense_cap ? kn.dense_cap : kDenseCapDefault;
-	const bool global_possible = kn.table == TAB_GLOBAL || (maxfrag > 3 && cap < (maxfrag - 3) / 2) ||
+	const bool global_possible = kn.table == TAB_GLOBAL || cap < max_ids(maxfrag) ||
 				     (kn.sample_min && maxfrag == kFragment);
 	const uint32_t spill = maxfrag == kFragment ? kn.spill_cap * 2 : 0; /* behind the ids / the global table */
 	return (global_possible ? 65536u : (ids < 1024 ? 1024u : ids)) + spill;
@@ -3405,37 +3499,45 @@ Workspace plan_workspace(uint32_t nblocks, uint32_t max_in_len, const Knobs &kn,
 }
 
 
-/* 0: the LDS serves one instruction's lanes in ascending order on this device (snappy_lds_order_probe);
- * checked once per device and process, on the caller's stream (one small launch and a 4-byte copy) */
-int lds_order_checked(hipStream_t st)
+/* Does the LDS of the current device serve one instruction's lanes in ascending order
+ * (snappy_lds_order_probe)?  Asked once per device and process, on a stream of its own: the first
+ * compress call on a device waits for two small launches and a 4-byte copy (about a millisecond; the
+ * caller's stream is not touched).  *ordered = 1 / 0; a negative return is a HIP failure, and the
+ * question is asked again by the next call. */
+int lds_order_probed(int *ordered)
 {
 	static std::mutex mu;
-	static int verdict[64]; /* 0 unknown, 1 good, -1 bad */
+	static int verdict[64]; /* 0 unknown, 1 ordered, -1 not */
 	int dev = 0;
 	if (!hip_ok(hipGetDevice(&dev), "hipGetDevice") || dev < 0 || dev >= 64)
 		return CSNAPPY_HIP_E_RUNTIME;
 	std::lock_guard<std::mutex> lock(mu);
 	if (verdict[dev] == 0) {
+		hipStream_t ps = nullptr;
 		uint32_t *d_bad = nullptr, h_bad = 1;
-		if (!hip_ok(hipMalloc(&d_bad, 4), "hipMalloc (LDS order probe)"))
+		hipDeviceProp_t prop;
+		if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties (LDS order probe)") ||
+		    !hip_ok(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking), "hipStreamCreate (LDS order probe)"))
 			return CSNAPPY_HIP_E_RUNTIME;
-		bool ok = hip_ok(hipMemsetAsync(d_bad, 0, 4, st), "hipMemsetAsync (LDS order probe)");
+		bool ok = hip_ok(hipMalloc(&d_bad, 4), "hipMalloc (LDS order probe)") &&
+			  hip_ok(hipMemsetAsync(d_bad, 0, 4, ps), "hipMemsetAsync (LDS order probe)");
 		if (ok) {
-			hipLaunchKernelGGL(snappy_lds_order_probe, dim3(512), dim3(64), 0, st, d_bad);
-			ok = hip_ok(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (LDS order probe)") &&
-			     hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize (LDS order probe)");
+			/* idle device: 512 waves; then every CU full of 10 KiB workgroups, twice over */
+			const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+			hipLaunchKernelGGL(snappy_lds_order_probe, dim3(512), dim3(64), 2 * kProbeEntries, ps, d_bad, 32u);
+			hipLaunchKernelGGL(snappy_lds_order_probe, dim3(cus * 32), dim3(64), 2 * kProbeEntries, ps, d_bad, 48u);
+			ok = hip_ok(hipGetLastError(), "launch snappy_lds_order_probe") &&
+			     hip_ok(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, ps), "hipMemcpyAsync (LDS order probe)") &&
+			     hip_ok(hipStreamSynchronize(ps), "hipStreamSynchronize (LDS order probe)");
 		}
-		(void)hipFree(d_bad);
+		if (d_bad)
+			(void)hipFree(d_bad);
+		(void)hipStreamDestroy(ps);
 		if (!ok)
 			return CSNAPPY_HIP_E_RUNTIME;
 		verdict[dev] = h_bad == 0 ? 1 : -1;
 	}
-	if (verdict[dev] < 0) {
-		snprintf(g_last_error, sizeof(g_last_error),
-			 "this device's LDS does not serve the lanes of one instruction in ascending order "
-			 "(snappy_lds_order_probe): the parsers of this build cannot run on it");
-		return CSNAPPY_HIP_E_RUNTIME;
-	}
+	*ordered = verdict[dev] > 0;
 	return 0;
 }
 
@@ -3565,8 +3667,13 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 		return CSNAPPY_HIP_E_ARG;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const ParsePlan P = plan_parse(p, max_fragment(max_in_len), kn);
-	if (P.tab != TAB_GLOBAL) {
-		const int rc = lds_order_checked(st);
+	/* every placement relies on the order in which the LDS serves one instruction's lanes (the tables
+	 * in LDS through their returning add and their stores, the global table through its returning
+	 * exchange): a device that does not keep it, or CSNAPPY_HIP_NO_LDS_ORDER=1, gets the parsers
+	 * that do without -- same bytes, several times slower */
+	int ordered = 0;
+	if (!kn.no_lds_order) {
+		const int rc = lds_order_probed(&ordered);
 		if (rc)
 			return rc;
 	}
@@ -3599,33 +3706,55 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.mode = mode;
 
 	/* (the s_memtime phase counters of tools/phase_lean.py exist for the dense and the global placement) */
-	const void *k2 = g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof)
-				    : reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
+	const void *k2 = !ordered ? reinterpret_cast<const void *>(snappy_parse_fragments_gtab_unordered)
+			 : g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof)
+				      : reinterpret_cast<const void *>(snappy_parse_fragments_gtab);
 	const void *k1 = P.tab == TAB_LDS_DENSE
-				 ? (g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof)
-					       : reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean))
-			 : P.tab == TAB_LDS_HASH ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean) : k2;
+				 ? (!ordered ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_unordered)
+				    : g_prof_buf ? reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof)
+						 : reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean))
+			 : P.tab == TAB_LDS_HASH
+				 ? (!ordered ? reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean_unordered)
+					     : reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean))
+				 : k2;
 	{
-		/* the kernels' dynamic-LDS limit is one attribute per kernel and process: raised once to the
-		 * most a workgroup can have, never per call (a call with a small table must not lower it
-		 * under another thread's launch) */
-		static std::once_flag once;
-		static bool attr_ok = false;
-		std::call_once(once, [] {
-			const void *ks[] = { reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean),
-					     reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof),
-					     reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean),
-					     reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
-					     reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof) };
-			attr_ok = true;
-			for (const void *k : ks)
-				attr_ok = attr_ok && hip_ok(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-										   (int)kLdsPerWorkgroupMax),
-							    "hipFuncSetAttribute");
-		});
-		if (!attr_ok)
+		/* the kernels' dynamic-LDS limit is an attribute per kernel and DEVICE: raised once per device
+		 * to the most a workgroup of that device can have, never per call (a call with a small table
+		 * must not lower it under another thread's launch) */
+		static std::mutex mu;
+		static int lds_limit[64]; /* per device: 0 not set yet, -1 failed, else the limit in bytes */
+		int dev = 0;
+		if (!hip_ok(hipGetDevice(&dev), "hipGetDevice") || dev < 0 || dev >= 64)
 			return CSNAPPY_HIP_E_RUNTIME;
-		if (P.lds_bytes > kLdsPerWorkgroupMax || P.g_lds_bytes > kLdsPerWorkgroupMax || P.lds_bytes_2 > kLdsPerWorkgroupMax)
+		int limit;
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			if (lds_limit[dev] == 0) {
+				const void *ks[] = { reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_prof),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_gtab),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_gtab_prof),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_dense_lean_unordered),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_hash_lean_unordered),
+						     reinterpret_cast<const void *>(snappy_parse_fragments_gtab_unordered) };
+				int optin = 0;
+				bool ok = hip_ok(hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev),
+						 "hipDeviceGetAttribute (LDS per workgroup)");
+				if (ok && (optin <= 0 || optin > (int)kLdsPerWorkgroupMax))
+					optin = (int)kLdsPerWorkgroupMax;
+				for (const void *k : ks)
+					ok = ok && hip_ok(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, optin),
+							  "hipFuncSetAttribute");
+				lds_limit[dev] = ok ? optin : -1;
+			}
+			limit = lds_limit[dev];
+			if (limit < 0)
+				lds_limit[dev] = 0; /* (a transient failure is tried again by the next call) */
+		}
+		if (limit < 0)
+			return CSNAPPY_HIP_E_RUNTIME;
+		if (P.lds_bytes > (uint32_t)limit || P.g_lds_bytes > (uint32_t)limit || P.lds_bytes_2 > (uint32_t)limit)
 			return CSNAPPY_HIP_E_ARG;
 	}
 

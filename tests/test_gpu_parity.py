@@ -867,6 +867,28 @@ def test_every_table_placement_is_bit_exact(torch, chk, placement, monkeypatch):
     assert sha(b"".join(blocks)) == g["sha256"]
 
 
+@pytest.mark.parametrize("placement", PLACEMENTS)
+def test_every_placement_without_the_lds_order(torch, chk, placement, monkeypatch):
+    """The fast parsers rely on the order in which the LDS serves the lanes of one instruction (measured on
+    gfx950, probed per device, promised by no manual).  A device that fails the probe -- or
+    CSNAPPY_HIP_NO_LDS_ORDER=1 -- gets parsers that do without it: every lane with a bucket is resolved
+    from the lower lanes' registers and one lane per slot stores.  Same bytes, every placement."""
+    monkeypatch.setenv("CSNAPPY_HIP_NO_LDS_ORDER", "1")
+    _force_placement(monkeypatch, placement)
+    xs = list(_ragged_cases(901, 24)) + list(_slot_sharing_cases(78, 25))
+    for p, mode in ((16, api.STREAM), (13, api.STREAM), (15, api.FRAGMENT)):
+        ys = [x[:32768] for x in xs] if mode == api.FRAGMENT else xs
+        host, lens = np.concatenate(ys), [len(y) for y in ys]
+        blocks, _, _ = gpu_compress(torch, host, lens, p, mode)
+        want = oracle_blocks(chk, host, lens, p, mode)
+        bad = [i for i, (a, b) in enumerate(zip(blocks, want)) if a != b]
+        assert not bad, (placement, p, mode, bad[:5], [lens[i] for i in bad[:5]])
+    g = GOLD["workloads"]["G_text_64k_p16"]
+    d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
+    blocks, _, _ = gpu_compress(torch, d_in.cpu().numpy(), [g["block"]] * g["nblocks"], g["p"], g["mode"])
+    assert sha(b"".join(blocks)) == g["sha256"]
+
+
 def test_block_longer_than_promised_is_refused_not_corrupted(torch, chk):
     """in_len[b] > max_in_len violates the batch call's precondition (the workspace is sized by
     max_in_len): that block gets out_len = 0xffffffff and its slot is not touched, its neighbours are
