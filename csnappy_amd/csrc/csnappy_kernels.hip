@@ -60,6 +60,9 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
 #ifndef CSNAPPY_PARSE_NOSPILLSTORE
 #define CSNAPPY_PARSE_NOSPILLSTORE 0
 #endif
+#ifndef CSNAPPY_FAST
+#define CSNAPPY_FAST 1 /* 0: no hand-written fast path in the dense parser (A/B, and the reference for its logic) */
+#endif
 #define DEVINL __device__ __forceinline__
 
 struct CompressArgs {
@@ -652,7 +655,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	}
 
 	/* FindMatchLength beyond the lane-local 16 bytes: 512 B per iteration, :252-295 */
-	auto extend = [&](uint32_t cnd, uint32_t base) -> uint32_t {
+	auto extend = [&](uint32_t cnd, uint32_t base) __attribute__((always_inline)) -> uint32_t {
 		const uint32_t ma = cnd + kLocalMatch, mb = base + kLocalMatch, lim = n - mb;
 		uint32_t done = 0;
 		for (;;) {
@@ -695,7 +698,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		uint32_t raw0, raw1, raw2, raw3, sid = kNoBucket;
 		uint32_t pos = 0;
 		bool valid = false;
-		auto place = [&]() {
+		auto place = [&]() __attribute__((always_inline)) {
 			pos = pz + lane;
 			valid = pos < ip_limit;
 			if (__builtin_expect(q1 > 32, 0)) {
@@ -727,9 +730,360 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		 * of the fragment's record region (which no record reaches), so that the number of memory
 		 * instructions behind the gather is the same on every path */
 		uint2 prec = make_uint2(0, 0);
-		uint32_t prec_idx = A.rec_cap - 1;
-#define CSNAPPY_FLUSH_PREC() (*reinterpret_cast<unsigned long long *>(R + prec_idx) = *reinterpret_cast<unsigned long long *>(&prec))
+		const uint32_t no_rec_off = (A.rec_cap - 1) * 8; /* byte offset of that slot */
+		uint32_t prec_off = no_rec_off;
+#define CSNAPPY_FLUSH_PREC()                                                                       \
+	(*reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(R) + prec_off) =      \
+		 *reinterpret_cast<unsigned long long *>(&prec))
+
+		/* ---- what a dense step knows about its lanes (set by the step's front half -- C++ below, or the
+		 * hand-written one of the fast path -- and used by the visits of special lanes and the back half) ---- */
+		uint32_t p0 = 0;                            /* position of lane 0 */
+		uint32_t me0 = 0, me1 = 0, me2 = 0, me3 = 0; /* the lane's own 16 bytes */
+		uint32_t slot = 0;                          /* its table slot (dense id, or hash) */
+		uint32_t mlen = 0, cl = 0, cand = 0, nx = 0; /* match length, lane behind the match, candidate, next stop */
+		uint32_t lim0 = 0, ulim = 64, t = 0;
+		uint64_t tmask = 0, cmask = 0, stopmask = 0, special = 0, taken = 0;
+
+		/* The hops of the walk, t = nx[t] until t >= 64, every lane passed marked in `taken`: the whole loop
+		 * is one asm block, so that the wait states are spelled out here and do not hang on what the
+		 * compiler happens to put between two of its iterations (its hazard recogniser does not look
+		 * inside inline asm).  A v_readlane whose lane select was written by the vector unit -- the
+		 * previous hop's v_readlane -- needs four wait states: s_nop 0, s_cmp, s_cbranch and the next
+		 * hop's mark are those four; the mark in FRONT of the v_readlane is also the one wait state the
+		 * first v_readlane needs behind the vector instruction that wrote nx.  t on entry comes from the
+		 * scalar unit (a constant, or scalar arithmetic), which needs none.  Five instructions a hop. */
+#define CSNAPPY_HOPS()                                                                             \
+	asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\tv_readlane_b32 %1, %2, %1\n\ts_nop 0\n\t"           \
+		     "s_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b"                                     \
+		     : "+s"(taken), "+s"(t) : "v"(nx) : "scc") /* do { taken |= 1ull << t; t = nx[t]; } while (t < 64) */
+
+		/* the next stop behind a copy that ends in front of lane cc, found on the scalar unit (behind a
+		 * visit): 64: the re-match probe falls outside the usable lanes; 65: none of the 33 probes
+		 * behind the copy is a stop; lane | 128: that stop is a special lane */
+		auto scalar_next = [&](uint32_t cc) __attribute__((always_inline)) -> uint32_t {
+			if (cc >= ulim)
+				return 64u;
+			const uint64_t rest = stopmask >> cc;
+			const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+			const uint32_t j = cc + fm;
+			if (fm > 32 || j > 63)
+				return 65u;
+			return j | (((uint32_t)(special >> j) & 1u) << 7);
+		};
+
+		/* ---- the walk met a special lane (t >= 128): a flagged one, or a match of the lane-local 16 bytes
+		 * that may be longer.  Settles it and walks on, until the walk leaves the step (t == 64 / 65). ---- */
+		auto visits = [&]() __attribute__((always_inline)) {
+			while (__builtin_expect(t >= 128, 0)) {
+				const uint32_t i = t & 63u;
+				uint32_t L = rdlane(mlen, i);
+				if (PROF)
+					pn_special++;
+				if ((cmask >> i) & 1) {
+					/* ---- the chain probes a flagged lane ----
+					 * Its candidate is the latest position inserted for its slot: the highest
+					 * lane below it that this step inserts (not strictly inside a copy of the
+					 * chain) and that has the same slot -- whose bytes are that lane's own 16
+					 * bytes -- else the table value it already compared with. */
+					const uint32_t slot_i = rdlane(slot, i);
+					uint64_t same = ballot64(slot == slot_i) & tmask & ((1ull << i) - 1);
+					/* A lane strictly inside the nearest taken copy below it was never inserted.  The
+					 * highest of `same` is tested on the scalar unit (it nearly always was inserted:
+					 * no LDS round trip then); if it was not, all of them are settled at once with a
+					 * ds_bpermute of the copies' ends (runs put the slot on every lane below: one by
+					 * one on the scalar unit they cost pages a quarter of their speed) */
+					if (same && taken) {
+						const uint32_t jh = 63u - (uint32_t)__builtin_clzll(same);
+						const uint64_t kb = taken & ((1ull << jh) - 1);
+						if (kb && jh + 1 < rdlane(cl, 63u - (uint32_t)__builtin_clzll(kb))) {
+							const uint64_t below = taken & lt_mask;
+							const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+							const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
+							same &= ~ballot64(below != 0 && lane + 1 < cprev);
+						}
+					}
+					if (same) {
+						const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
+						const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
+						const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
+						const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
+						const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
+						const uint32_t ml = common_prefix16(ylo, yhi);
+						L = rdlane(ml, i);
+						if (lane == i)
+							cand = p0 + j;
+					}
+					if (L < 4) {
+						/* no match: on to the next stop of the current window */
+						const uint32_t lim_cur = taken ? rdlane(cl, 63u - (uint32_t)__builtin_clzll(taken)) + 32 : lim0;
+						const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
+						const uint32_t i2 = m ? first_lane(m) : 64u;
+						t = (i2 > lim_cur || i2 > 63) ? 65u : i2 | (((uint32_t)(special >> (i2 & 63u)) & 1u) << 7);
+						if (t < 64)
+							CSNAPPY_HOPS();
+						continue;
+					}
+				}
+				if (L == kLocalMatch && p0 + i + kLocalMatch < n) {
+					/* longer than the lane-local cap: extend it wave-wide (it may leave the step) */
+					L = kLocalMatch + extend(rdlane(cand, i), p0 + i);
+				}
+				if (lane == i) {
+					mlen = L;
+					cl = lane + L;
+				}
+				taken |= 1ull << i;
+				t = scalar_next(i + L);
+				if (t < 64)
+					CSNAPPY_HOPS();
+			}
+		};
+
+		/* ==================================================================================
+		 * The fast path (round 6): the common case of a dense step -- table in LDS by dense ids, no
+		 * spill-over, all 64 lanes in front of the scan limit -- written by hand, two asm blocks:
+		 *   FRONT  table read + returning add, check bit, candidate gather, the previous step's record
+		 *          store behind it, flagged lanes, 16-byte comparison, stop / special masks, next-stop
+		 *          table, the walk's plain hops                       (what the C++ below does up to
+		 *          CSNAPPY_HOPS; same values in the same variables, so visits() serves both)
+		 *   BACK   cursor, the next step's loads, records, commit     (the C++ behind visits())
+		 * and a loop of [BACK of step k; FRONT of step k + 1] as ONE block, so that the loads BACK
+		 * requests are waited for inside the block that issued them.  Between the blocks C++ only tests
+		 * for a special lane (visits()) and for a step without any copy (settled in a few lines of C++).
+		 * 239 -> ~155 instructions per step; the compiler's version spends the difference on boolean
+		 * round trips (v_cndmask 0/1 + v_cmp for every ballot of a combined predicate), 64-bit lane-mask
+		 * tests in vector registers where v_cndmask takes the mask as it is, v_mbcnt, selects where the
+		 * dummy table entry needs none, a dozen copies at the loop's head and back edge, and s_nops where
+		 * independent instructions fit.
+		 * Wait states are spelled out (gfx940 family): vector-written SGPR -> vector read: 2; -> v_readlane
+		 * lane select: 4; vector-written VGPR -> DPP read: 2, -> v_readlane: 1.  Scratch registers are fixed
+		 * (v52-v67, s70-s79, vcc) and named as clobbers or through register variables; the dense kernel
+		 * has 67 VGPRs anyway (its prologue).
+		 * ================================================================================== */
+		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
+		/* a step is fast-eligible when it is dense (q1 <= 32) and pz + 64 < ip_limit: every lane is valid,
+		 * and so is every lane's p0 + lane + 16 < n */
+		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
+		const uint32_t limit64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ip_limit > 64 ? ip_limit - 64 : 0u));
+
 		while (!fin && ++guard <= n) {
+			if constexpr (FAST) if (q1 <= 32 && pz < limit64) {
+				/* (all of this block's variables are the fast path's own; the general step below does
+				 * not see them) */
+				register uint32_t x0 asm("v52"), x1 asm("v53"), x2 asm("v54"), x3 asm("v55");
+				register uint32_t px asm("v58"), py asm("v59");
+				uint32_t a16, a32, one, mine, go = 0;
+				uint32_t k32 = 32, thr = lane == 0 ? 0u : 0x8000u;
+				const uint32_t shm1 = shift - 1, mul = kHashMul, safemax = n - 16;
+				px = prec.x;
+				py = prec.y;
+#define CSNAPPY_FRONT_TEXT                                                                                             \
+	"s_sub_u32 %[lim0], 33, %[q1]\n\t"                 /* probes the scan in progress has left */                      \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
+	"v_lshlrev_b32_e32 %[a16], 1, %[sid]\n\t"          /* my table entry (id 0: the dummy) */                          \
+	"ds_read_u16 v64, %[a16]\n\t"                                                                                      \
+	"v_and_b32_e32 %[a32], 0xfffc, %[a16]\n\t"         /* its dword */                                                 \
+	"v_lshlrev_b32_e32 v66, 4, %[sid]\n\t"             /* bits 4:0 = 16 * (id & 1) */                                  \
+	"v_lshlrev_b32_e64 %[one], v66, 1\n\t"             /* 1 in my half */                                              \
+	"ds_add_rtn_u32 v65, %[a32], %[one]\n\t"           /* comes back with the lower lanes' ones in it */               \
+	"v_writelane_b32 %[k32], %[lim0], 0\n\t"           /* lane 0 searches what is left of the scan, the others 33 probes */ \
+	"v_mul_lo_u32 v67, %[me0], %[mul]\n\t"                                                                             \
+	"v_bfe_u32 v67, v67, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	"v_cmp_ne_u32_e64 %[tmask], 0, %[sid]\n\t"         /* lanes with a bucket */                                       \
+	"v_lshl_or_b32 %[mine], v67, 15, %[pos]\n\t"       /* my entry, if I am inserted */                                \
+	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
+	"v_xor_b32_e32 v67, v64, %[mine]\n\t"                                                                              \
+	"v_and_b32_e32 %[cand], 0x7fff, v64\n\t"                                                                           \
+	"v_cmp_lt_u32_e32 vcc, v67, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_and_b64 s[70:71], vcc, %[tmask]\n\t"            /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v67, 0, %[cand], s[70:71]\n\t"                                                                  \
+	"global_load_dwordx4 v[60:63], v67, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 %[precoff], v[58:59], %[R]\n\t" /* the previous step's records, behind the gather */         \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_bfe_u32 v65, v65, v66, 16\n\t"                  /* my half as the add found it */                               \
+	"v_cmp_ne_u32_e32 vcc, v65, v64\n\t"               /* not the entry: a lower lane has my slot */                   \
+	"s_and_b64 %[cmask], vcc, %[tmask]\n\t"            /* flagged lanes */                                             \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */                  \
+	"v_xor_b32_e32 v60, v60, %[me0]\n\t"                                                                               \
+	"v_xor_b32_e32 v61, v61, %[me1]\n\t"                                                                               \
+	"v_xor_b32_e32 v62, v62, %[me2]\n\t"                                                                               \
+	"v_xor_b32_e32 v63, v63, %[me3]\n\t"                                                                               \
+	"v_ffbl_b32_e32 v60, v60\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v61, v61\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v62, v62\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v63, v63\n\t"                                                                                      \
+	"v_add_u32_e64 v61, v61, 32 clamp\n\t"                                                                             \
+	"v_add_u32_e64 v63, v63, 32 clamp\n\t"                                                                             \
+	"v_min3_u32 v60, v60, v61, 64\n\t"                 /* equal low bits of bytes 0..7 (64: all) */                    \
+	"v_min3_u32 v62, v62, v63, 64\n\t"                 /* ... of bytes 8..15 */                                        \
+	"v_lshrrev_b32_e32 v61, 6, v60\n\t"                                                                                \
+	"v_mad_u32_u24 v60, v61, v62, v60\n\t"             /* + the high half when the low one is all equal */             \
+	"v_lshrrev_b32_e32 v60, 3, v60\n\t"                                                                                \
+	"v_cndmask_b32_e64 %[mlen], 0, v60, s[70:71]\n\t"  /* lane-local match length, 0..16 */                            \
+	"v_cmp_lt_u32_e64 %[stop], 3, %[mlen]\n\t"         /* matches */                                                   \
+	"v_cmp_eq_u32_e32 vcc, 16, %[mlen]\n\t"            /* may be longer */                                             \
+	"v_add_u32_e32 %[cl], %[lane], %[mlen]\n\t"        /* lane of the re-match probe behind my match */                \
+	"s_or_b64 %[stop], %[stop], %[cmask]\n\t"          /* stops of the chain: matches and flagged lanes */             \
+	"s_or_b64 %[special], vcc, %[cmask]\n\t"           /* ... that need a visit */                                     \
+	"v_lshrrev_b64 v[56:57], %[cl], %[stop]\n\t"                                                                       \
+	"v_sub_u32_e32 v62, 63, %[cl]\n\t"                 /* lanes left behind my match (negative: none) */               \
+	"v_ffbl_b32_e32 v57, v57\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v56, v56\n\t"                                                                                      \
+	"v_add_u32_e64 v57, v57, 32 clamp\n\t"                                                                             \
+	"v_min_i32_e32 v62, v62, %[k32]\n\t"               /* ... and probes */                                            \
+	"v_min3_u32 v56, v56, v57, 64\n\t"                 /* distance to the next stop */                                 \
+	"v_add_u32_e32 v63, %[cl], v56\n\t"                /* its lane */                                                  \
+	"v_cmp_le_i32_e32 vcc, v56, v62\n\t"                                                                               \
+	"v_lshrrev_b64 v[60:61], v63, %[special]\n\t"                                                                      \
+	"v_and_b32_e32 v60, 1, v60\n\t"                                                                                    \
+	"v_lshl_or_b32 v64, v60, 7, v63\n\t"               /* lane | 128: a special one */                                 \
+	"v_cndmask_b32_e32 %[nx], 64, v64, vcc\n\t"        /* next stop of the chain if my match is taken (64: none here) */ \
+	"s_mov_b64 %[taken], 0\n\t"                                                                                        \
+	"v_readlane_b32 %[t], %[nx], 0\n\t"                /* the walk: lane 0 holds the first stop */                     \
+	"s_nop 0\n\t"                                                                                                      \
+	"s_cmp_lt_u32 %[t], 64\n\t"                                                                                        \
+	"s_cbranch_scc0 9f\n\t"                          /* none, or a special lane: C++ (taken == 0) */                 \
+	"1:\n\t"                                                                                                           \
+	"s_bitset1_b64 %[taken], %[t]\n\t"                                                                                 \
+	"v_readlane_b32 %[t], %[nx], %[t]\n\t"                                                                             \
+	"s_nop 0\n\t"                                                                                                      \
+	"s_cmp_lt_u32 %[t], 64\n\t"                                                                                        \
+	"s_cbranch_scc1 1b\n\t"
+#define CSNAPPY_FAST_CLOBBERS                                                                                          \
+	"v56", "v57", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "s70", "s71", "s72", "s73", "s74", "s75",  \
+		"s76", "s77", "s78", "s79", "vcc", "scc", "memory"
+				/* FRONT of the first fast step (its loads came from place(): the compiler has waited for them) */
+				asm volatile(CSNAPPY_FRONT_TEXT "9:\n\t"
+					     : [mlen] "=&v"(mlen), [cl] "=&v"(cl), [cand] "=&v"(cand), [nx] "=&v"(nx), [a16] "=&v"(a16),
+					       [a32] "=&v"(a32), [one] "=&v"(one), [mine] "=&v"(mine), [tmask] "=&s"(tmask),
+					       [cmask] "=&s"(cmask), [stop] "=&s"(stopmask), [special] "=&s"(special),
+					       [taken] "=&s"(taken), [t] "=&s"(t), [lim0] "=&s"(lim0), [k32] "+v"(k32)
+					     : [me0] "v"(raw0), [me1] "v"(raw1), [me2] "v"(raw2), [me3] "v"(raw3), [sid] "v"(sid),
+					       [pos] "v"(pos), [q1] "s"(q1), [precoff] "v"(prec_off), "v"(px), "v"(py), [src] "s"(src),
+					       [R] "s"(R), [shm1] "s"(shm1), [mul] "s"(mul), [thr] "v"(thr), [lane] "v"(lane)
+					     : CSNAPPY_FAST_CLOBBERS);
+				me0 = raw0;
+				me1 = raw1;
+				me2 = raw2;
+				me3 = raw3;
+				slot = sid;
+				ulim = 64;
+				for (;;) {
+					p0 = pz;
+					if (__builtin_expect(t >= 128, 0))
+						visits();
+					/* (every scalar operand of the block below has a value on either path: an undefined one
+					 * reaches the block as a vector register, which it cannot take) */
+					uint32_t sidn = sid, posn = pos, offn = prec_off, nemit = next_emit;
+					go = 99;
+					if (__builtin_expect(taken == 0, 0)) {
+						/* no copy in this step: the scan goes on behind its last probe (:535-552); nothing
+						 * to record; every lane up to that probe is inserted */
+						const uint32_t e = min(lim0, 63u);
+						q1 += e;
+						pz += e;
+						prec = make_uint2(0, 0);
+						prec_off = no_rec_off;
+						(void)atomicSub(&tab32[slot >> 1], 1u << ((slot & 1u) << 4));
+						wave_lds_fence();
+						if (lane <= e)
+							tab[slot] = (uint16_t)mine;
+						wave_lds_fence();
+					} else {
+					/* BACK of this step, FRONT of the next, and round again for as long as the walk meets
+					 * nothing special.  Leaves with go >= 33 behind a BACK (the next step is not for the
+					 * fast path), else behind a FRONT whose walk stands at a special lane (t >= 128) or
+					 * found no first stop (taken == 0). */
+					asm volatile(
+						"0:\n\t"
+						"s_flbit_i32_b64 s72, %[taken]\n\t"
+						"s_xor_b32 s72, s72, 63\n\t"                     /* the last copy's lane */
+						"v_mov_b32_e32 v66, %[nemit]\n\t"                /* where the pending literal starts */
+						"v_readlane_b32 s73, %[cl], s72\n\t"             /* c: the lane behind the last copy */
+						"v_add_u32_e32 v67, %[p0], %[cl]\n\t"            /* where my copy ends */
+						"s_bcnt1_i32_b64 s78, %[taken]\n\t"
+						"v_cndmask_b32_e64 v67, v66, v67, %[taken]\n\t"
+						"s_add_u32 %[nemit], %[p0], s73\n\t"             /* next_emit: behind the last copy */
+						"s_add_u32 s74, s73, 32\n\t"
+						"v_max_u32_dpp v67, v67, v67 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+						"s_min_u32 s74, s74, 63\n\t"                     /* e: the last lane the step probes */
+						"s_add_u32 s75, s73, -1\n\t"                     /* c - 1 */
+						"v_max_u32_dpp v67, v67, v67 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+						"s_sub_u32 s76, s74, s75\n\t"                    /* probes of the scan behind the copy: e - c + 1 */
+						"s_cmp_ge_u32 s73, 64\n\t"                       /* the copy leaves the step: re-match probe next */
+						"v_max_u32_dpp v67, v67, v67 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+						"s_cselect_b32 s75, s75, s74\n\t"                /* lane 0 of the next step */
+						"s_cselect_b32 %[q1], 0, s76\n\t"
+						"v_max_u32_dpp v67, v67, v67 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+						"s_cselect_b32 s72, s72, s74\n\t"                /* e_final: the last lane that is inserted */
+						"s_mov_b64 vcc, %[taken]\n\t"
+						"v_max_u32_dpp v67, v67, v67 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+						"v_mbcnt_lo_u32_b32 v56, vcc_lo, 0\n\t"
+						"v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t"        /* taken lanes below me */
+						"v_max_u32_dpp v67, v67, v67 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+						"v_lshl_or_b32 v58, %[cand], 16, %[pos]\n\t"     /* record: base | cand << 16 */
+						"v_add_u32_e32 v57, 1, %[pos]\n\t"
+						"v_mov_b32_dpp v66, v67 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */
+						"s_add_u32 %[p0], %[p0], s75\n\t"                /* pz */
+						"v_add_lshl_u32 v56, v56, %[nev], 3\n\t"         /* my record's byte offset */
+						"s_add_u32 %[nev], %[nev], s78\n\t"
+						"v_lshl_or_b32 v59, v66, 16, %[mlen]\n\t"        /* record: copy_len | lit_start << 16 */
+						"v_cmp_lt_u32_e64 s[70:71], v57, v66\n\t"        /* strictly inside a copy: never inserted */
+						"v_cndmask_b32_e64 %[precoff], %[norec], v56, %[taken]\n\t"
+						"s_cmp_lt_u32 %[p0], %[limit64]\n\t"
+						"s_cselect_b32 %[go], %[q1], 99\n\t"             /* next step fast too: < 33 */
+						"v_add_u32_e32 %[pos], %[p0], %[lane]\n\t"       /* the next step's positions */
+						"v_min_u32_e32 v57, %[safemax], %[pos]\n\t"      /* (clamped: harmless loads when the fast path ends here) */
+						"global_load_dwordx4 v[52:55], v57, %[src]\n\t"
+						"v_lshlrev_b32_e32 v56, 1, v57\n\t"
+						"global_load_ushort %[sid], v56, %[ids]\n\t"
+						"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"         /* lanes up to e_final */
+						"ds_sub_u32 %[a32], %[one]\n\t"                  /* the adds are taken back */
+						"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"        /* inserted lanes */
+						"s_mov_b64 exec, s[70:71]\n\t"
+						"ds_write_b16 %[a16], %[mine]\n\t"               /* (of several with one slot the highest stays) */
+						"s_mov_b64 exec, -1\n\t"
+						"s_cmp_lt_u32 %[go], 33\n\t"
+						"s_cbranch_scc0 9f\n\t"
+						CSNAPPY_FRONT_TEXT
+						"s_cmp_eq_u32 %[t], 64\n\t"                   /* the walk left the step: its BACK (else a special lane: C++) */
+						"s_cbranch_scc1 0b\n\t"
+						"9:\n\t"
+						: [mlen] "+v"(mlen), [cl] "+v"(cl), [cand] "+v"(cand), [nx] "=&v"(nx), [a16] "+v"(a16),
+						  [a32] "+v"(a32), [one] "+v"(one), [mine] "+v"(mine), [tmask] "=&s"(tmask),
+						  [cmask] "=&s"(cmask), [stop] "=&s"(stopmask), [special] "=&s"(special),
+						  [taken] "+s"(taken), [t] "=&s"(t), [lim0] "=&s"(lim0), [k32] "+v"(k32),
+						  [me0] "=&v"(x0), [me1] "=&v"(x1), [me2] "=&v"(x2), [me3] "=&v"(x3), [sid] "=&v"(sidn),
+						  [pos] "+v"(posn), [precoff] "=&v"(offn), "=&v"(px), "=&v"(py), [p0] "+s"(pz), [q1] "+s"(q1),
+						  [nemit] "+s"(nemit), [nev] "+s"(nev), [go] "=&s"(go)
+						: [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shm1), [mul] "s"(mul), [thr] "v"(thr),
+						  [lane] "v"(lane), [norec] "v"(no_rec_off), [limit64] "s"(limit64), [safemax] "s"(safemax)
+						: CSNAPPY_FAST_CLOBBERS);
+					next_emit = nemit;
+					pos = posn;
+					prec_off = offn;
+					if (go >= 33) {
+						/* the fast path ends here: the loads BACK requested are still on their way */
+						asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(sidn));
+						prec = make_uint2(px, py);
+					}
+					}
+					if (go >= 33) {
+						fin = pz + 1 >= ip_limit;
+						place();
+						break;
+					}
+					me0 = x0;
+					me1 = x1;
+					me2 = x2;
+					me3 = x3;
+					slot = sid = sidn;
+				}
+				continue;
+			}
+#undef CSNAPPY_FRONT_TEXT
+#undef CSNAPPY_FAST_CLOBBERS
 			tick(0); /* (rest of the previous step: commit) */
 			if (PROF) {
 				asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
@@ -738,19 +1092,22 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			}
 			tick(1); /* wait for the step's own bytes and ids */
 			const bool sparse_c = q1 > 32;
-			const uint32_t p0 = pz; /* dense: position of lane 0 */
+			p0 = pz; /* dense: position of lane 0 */
 			const uint32_t pos_c = pos;
 			const bool valid_c = valid;
-			const uint32_t me0 = raw0, me1 = raw1, me2 = raw2, me3 = raw3;
+			me0 = raw0;
+			me1 = raw1;
+			me2 = raw2;
+			me3 = raw3;
 			const uint32_t prod = me0 * kHashMul;
-			const uint32_t slot = DENSE ? sid : prod >> shift;
+			slot = DENSE ? sid : prod >> shift;
 			const bool tabbed = DENSE ? valid_c && slot != kNoBucket : valid_c;
 			const uint32_t chk = (prod >> (shift - 1)) & 1u;
 			const uint32_t mine16 = pos_c | (chk << 15); /* my table entry, if I am inserted */
 			const bool spilled = SPILL && tabbed && slot >= dense_cap;
 			const bool in_lds = !GTAB && tabbed && !spilled;
-			uint32_t cand, raw16 = 0;
-			uint64_t cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
+			uint32_t raw16 = 0;
+			cmask = 0; /* lanes that share their slot with a LOWER lane of the step ("flagged") */
 			uint32_t bumped = 0;
 			uint32_t key = 0;
 			uint32_t xold = 0;
@@ -794,10 +1151,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			const bool maybe = tabbed && (CHK0_INIT ? cand >> 15 : (cand ? cand >> 15 : chk0)) == chk;
 			cand &= 0x7fffu;
 			uint4 w4 = make_uint4(0, 0, 0, 0);
-			uint64_t tmask = 0;
+			tmask = 0;
 			/* the lanes with a bucket, and those that share it with a lower lane (behind the gather's
 			 * issue in either kind of step: the kinds are told apart ONCE per step) */
-			auto step_flags = [&]() {
+			auto step_flags = [&]() __attribute__((always_inline)) {
 				tmask = ballot64(tabbed);
 				if (!ORD) {
 					cmask = tmask & ~1ull; /* (lane 0 has no lower lane) */
@@ -838,27 +1195,27 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint64_t imask = ~ballot64(valid_c);
 				const uint32_t c1 = cmask ? first_lane(cmask) : 64u;
 				const uint32_t v = imask ? first_lane(imask) : 64u;
-				const uint32_t ulim = min(c1, v);
-				const bool gathered = lane < ulim && maybe;
+				const uint32_t ulim_s = min(c1, v);
+				const bool gathered = lane < ulim_s && maybe;
 				__builtin_memcpy(&w4, src + (gathered ? cand : 0u), 16);
 				CSNAPPY_FLUSH_PREC();
 				const uint64_t xlo = ((uint64_t)(me1 ^ w4.y) << 32) | (me0 ^ w4.x);
 				const uint64_t xhi = ((uint64_t)(me3 ^ w4.w) << 32) | (me2 ^ w4.z);
-				const uint32_t mlen = gathered ? common_prefix16(xlo, xhi) : 0u;
-				const uint64_t matchmask = ballot64(lane < ulim && mlen >= 4);
+				const uint32_t mlen_s = gathered ? common_prefix16(xlo, xhi) : 0u;
+				const uint64_t matchmask = ballot64(lane < ulim_s && mlen_s >= 4);
 				if (matchmask == 0) {
-					e_final = ulim - 1; /* (ulim == 0 cannot happen: lane 0 is never flagged, and an invalid lane 0 ended the scan before) */
-					if (ulim == v && v < 64)
+					e_final = ulim_s - 1; /* (ulim_s == 0 cannot happen: lane 0 is never flagged, and an invalid lane 0 ended the scan before) */
+					if (ulim_s == v && v < 64)
 						fin = true; /* next probe is past ip_limit: goto emit_remainder, :543-544 */
 					else {
-						q1 += ulim;
-						pz += ulim;
+						q1 += ulim_s;
+						pz += ulim_s;
 					}
 				} else {
 					const uint32_t i = first_lane(matchmask);
 					e_final = i;
 					const uint32_t base = rdlane(pos_c, i), cnd = rdlane(cand, i);
-					uint32_t L = rdlane(mlen, i);
+					uint32_t L = rdlane(mlen_s, i);
 					if (L == kLocalMatch && base + L < n)
 						L += extend(cnd, base);
 					if (lane == 0)
@@ -878,7 +1235,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				CSNAPPY_FLUSH_PREC();
 				step_flags();
 				tick(2); /* filters + table */
-				const uint32_t ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
+				ulim = min(64u, ip_limit - p0); /* lanes in front of the scan limit */
 				/* (until round 5 the id lines two steps ahead were touched here, behind the gather: 9.00
 				 * against 9.14 ms per GiB of text in round 3; with a step a fifth shorter the four
 				 * instructions cost more than the touch saves: 9.30 against 9.48.  For small fragments
@@ -899,15 +1256,15 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				 * exec-mask region -- three scalar instructions and a branch.  Lane 0 is insert-only.) */
 				uint32_t cp16 = common_prefix16(xlo, xhi);
 				asm volatile("" : "+v"(cp16));
-				uint32_t mlen = (maybe && lane != 0) ? cp16 : 0u;
+				mlen = (maybe && lane != 0) ? cp16 : 0u;
 				const uint64_t matchmask = ballot64(mlen >= 4);
 				if (PROF)
 					pn_match4 += __builtin_popcountll(matchmask);
 				/* flagged lanes are stops of the chain like matches: what they hold is decided
 				 * when (and if) the chain gets there */
-				const uint64_t stopmask = matchmask | cmask;
-				const uint64_t special = ballot64(mlen == kLocalMatch && p0 + lane + kLocalMatch < n) | cmask;
-				uint32_t cl = lane + mlen; /* lane of the re-match probe after my match */
+				stopmask = matchmask | cmask;
+				special = ballot64(mlen == kLocalMatch && p0 + lane + kLocalMatch < n) | cmask;
+				cl = lane + mlen; /* lane of the re-match probe after my match */
 				/* c = lane behind a copy: the next stop of the chain.  64: the re-match probe falls
 				 * outside the usable lanes; 65: none of the 33 probes behind the copy is a stop;
 				 * lane | 128: that stop is a special lane */
@@ -915,8 +1272,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				 * are what is left of the current scan's stride-1 probes, so it is the same search
 				 * with cl = 0 and that many probes (the scalar unit did this until round 5: a dozen
 				 * instructions of its own per step) */
-				const uint32_t lim0 = 33 - q1;
-				uint32_t nx;
+				lim0 = 33 - q1;
 				{
 					const uint64_t rest = stopmask >> (cl & 63u);
 					uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
@@ -928,100 +1284,15 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					asm volatile("" : "+v"(inner)); /* (a select below, not an exec-mask region around the above) */
 					nx = cl >= ulim ? 64u : inner;
 				}
-				auto scalar_next = [&](uint32_t cc) -> uint32_t {
-					if (cc >= ulim)
-						return 64u;
-					const uint64_t rest = stopmask >> cc;
-					const uint32_t fm = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-					const uint32_t j = cc + fm;
-					if (fm > 32 || j > 63)
-						return 65u;
-					return j | (((uint32_t)(special >> j) & 1u) << 7);
-				};
-				uint32_t t = 0; /* (the walk starts AT lane 0, whose entry is the first stop) */
-				uint64_t taken = 0; /* lanes whose match is part of the chain */
+				t = 0; /* (the walk starts AT lane 0, whose entry is the first stop) */
+				taken = 0; /* lanes whose match is part of the chain */
 				tick(4); /* match lengths, next-stop table */
 				/* plain matches: hop from match to match (unrolling this loop four times was
-				 * measured in round 3: no gain) */
-	/* The hops of the walk, t = nx[t] until t >= 64, every lane passed marked in `taken`: the whole loop
-	 * is one asm block, so that the wait states are spelled out here and do not hang on what the
-	 * compiler happens to put between two of its iterations (its hazard recogniser does not look
-	 * inside inline asm).  A v_readlane whose lane select was written by the vector unit -- the
-	 * previous hop's v_readlane -- needs four wait states: s_nop 0, s_cmp, s_cbranch and the next
-	 * hop's mark are those four; the mark in FRONT of the v_readlane is also the one wait state the
-	 * first v_readlane needs behind the vector instruction that wrote nx.  t on entry comes from the
-	 * scalar unit (a constant, or scalar arithmetic), which needs none.  Five instructions a hop. */
-#define CSNAPPY_HOPS()                                                                             \
-	asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\tv_readlane_b32 %1, %2, %1\n\ts_nop 0\n\t"           \
-		     "s_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b"                                     \
-		     : "+s"(taken), "+s"(t) : "v"(nx) : "scc") /* do { taken |= 1ull << t; t = nx[t]; } while (t < 64) */
-				/* (the walk of a step without special lanes -- four steps in five -- is this loop alone) */
+				 * measured in round 3: no gain; the walk of a step without special lanes -- four
+				 * steps in five -- is this loop alone) */
 				CSNAPPY_HOPS();
 				taken &= ~1ull; /* (lane 0 is where the walk starts, not a match) */
-				while (__builtin_expect(t >= 128, 0)) {
-					const uint32_t i = t & 63u;
-					uint32_t L = rdlane(mlen, i);
-					if (PROF)
-						pn_special++;
-					if ((cmask >> i) & 1) {
-						/* ---- the chain probes a flagged lane ----
-						 * Its candidate is the latest position inserted for its slot: the highest
-						 * lane below it that this step inserts (not strictly inside a copy of the
-						 * chain) and that has the same slot -- whose bytes are that lane's own 16
-						 * bytes -- else the table value it already compared with. */
-						const uint32_t slot_i = rdlane(slot, i);
-						uint64_t same = ballot64(slot == slot_i) & tmask & ((1ull << i) - 1);
-						/* A lane strictly inside the nearest taken copy below it was never inserted.  The
-						 * highest of `same` is tested on the scalar unit (it nearly always was inserted:
-						 * no LDS round trip then); if it was not, all of them are settled at once with a
-						 * ds_bpermute of the copies' ends (runs put the slot on every lane below: one by
-						 * one on the scalar unit they cost pages a quarter of their speed) */
-						if (same && taken) {
-							const uint32_t jh = 63u - (uint32_t)__builtin_clzll(same);
-							const uint64_t kb = taken & ((1ull << jh) - 1);
-							if (kb && jh + 1 < rdlane(cl, 63u - (uint32_t)__builtin_clzll(kb))) {
-								const uint64_t below = taken & lt_mask;
-								const uint32_t jprev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-								const uint32_t cprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jprev << 2), (int)cl);
-								same &= ~ballot64(below != 0 && lane + 1 < cprev);
-							}
-						}
-						if (same) {
-							const uint32_t j = 63u - (uint32_t)__builtin_clzll(same);
-							const uint32_t o0 = rdlane(me0, j), o1 = rdlane(me1, j);
-							const uint32_t o2 = rdlane(me2, j), o3 = rdlane(me3, j);
-							const uint64_t ylo = ((uint64_t)(me1 ^ o1) << 32) | (me0 ^ o0);
-							const uint64_t yhi = ((uint64_t)(me3 ^ o3) << 32) | (me2 ^ o2);
-							const uint32_t ml = common_prefix16(ylo, yhi);
-							L = rdlane(ml, i);
-							if (lane == i)
-								cand = p0 + j;
-						}
-						if (L < 4) {
-							/* no match: on to the next stop of the current window */
-							const uint32_t lim_cur = taken ? rdlane(cl, 63u - (uint32_t)__builtin_clzll(taken)) + 32 : lim0;
-							const uint64_t m = i < 63 ? stopmask & ((~0ull) << (i + 1)) : 0;
-							const uint32_t i2 = m ? first_lane(m) : 64u;
-							t = (i2 > lim_cur || i2 > 63) ? 65u : i2 | (((uint32_t)(special >> (i2 & 63u)) & 1u) << 7);
-							if (t < 64)
-								CSNAPPY_HOPS();
-							continue;
-						}
-					}
-					if (L == kLocalMatch && p0 + i + kLocalMatch < n) {
-						/* longer than the lane-local cap: extend it wave-wide (it may leave the step) */
-						L = kLocalMatch + extend(rdlane(cand, i), p0 + i);
-					}
-					if (lane == i) {
-						mlen = L;
-						cl = lane + L;
-					}
-					taken |= 1ull << i;
-					t = scalar_next(i + L);
-					if (t < 64)
-						CSNAPPY_HOPS();
-				}
-#undef CSNAPPY_HOPS
+				visits();
 				/* ---- where the chain left the step (selects, no branches: this is scalar code) ----
 				 * t == 64: the last copy ends at or behind the usable lanes: re-match probe next
 				 * (:585-594).  t == 65: the current window (the 33 probes behind the last copy, or what
@@ -1091,7 +1362,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			if (PROF && sparse_c)
 				pn_sparse++;
 			prec = rec;
-			prec_idx = rec_mine ? rec_idx : A.rec_cap - 1;
+			prec_off = rec_mine ? rec_idx * 8 : no_rec_off;
 			/* commit table[slot] = position for every lane that was probed or inserted
 			 * (:550, :589, :593): lanes 0..e_final except those inside a copy */
 			bool commit = lane <= e_final && !inside && tabbed;
@@ -1136,6 +1407,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				spill[slot - dense_cap] = (uint16_t)mine16;
 			wave_lds_fence();
 		}
+#undef CSNAPPY_HOPS
 		CSNAPPY_FLUSH_PREC();
 #undef CSNAPPY_FLUSH_PREC
 		stuck = !fin;
