@@ -339,7 +339,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", dest="gather", action="store_false")
     ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=None,
                     help="behind the headline measurement, measure the other BASELINE.json configurations briefly "
-                         "(3 steps each) and add them to the record as `other_configs`.  Default: on for the "
+                         "(10 steps each) and add them to the record as `other_configs`.  Default: on for the "
                          "default 1-GPU text run, off otherwise")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
     ap.add_argument("--other-scale", type=float, default=1.0, help=argparse.SUPPRESS)  # tests: shrink the other configs
@@ -544,7 +544,7 @@ def run(args, eng, dist, rank, world):
         del d_in, d_out, d_back, cap, status, produced, b
         if hasattr(torch, "cuda") and torch.cuda.is_available():
             torch.cuda.empty_cache()
-        out["other_configs"] = measure_other_configs(eng, 3, args.other_scale)
+        out["other_configs"] = measure_other_configs(eng, 10, args.other_scale)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(kind, seed, block, p, mode, nb, args.cpu_seconds, urls)

@@ -243,7 +243,8 @@ def _stream():
 
 
 def workspace_size(nblocks, max_in_len, launch_gib=1):
-    """Scratch for launches of up to launch_gib GiB of input (1: the least the batch call accepts)."""
+    """Scratch for launches of up to launch_gib GiB of input (0: launches of 32 768 fragments whatever
+    their size -- csnappy_hip_compress_workspace_size, the least the batch call accepts)."""
     return lib().csnappy_hip_compress_workspace_size_for(nblocks, max_in_len, launch_gib)
 
 

@@ -3923,7 +3923,8 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	if (nblocks == 0)
 		return 0;
 	/* the largest launches the caller's workspace has room for (csnappy_hip_compress_workspace_size_for);
-	 * csnappy_hip_compress_workspace_size() -- launches of 1 GiB -- is the least that is accepted */
+	 * csnappy_hip_compress_workspace_size() -- launches of 32 768 fragments whatever their size -- is the
+	 * least that is accepted */
 	Workspace W = plan_workspace(nblocks, max_in_len, kn, 0);
 	if (workspace_bytes < W.total || (reinterpret_cast<uintptr_t>(d_workspace) & 255))
 		return CSNAPPY_HIP_E_WORKSPACE;

@@ -15,8 +15,12 @@
  * (out + out_off[b]); results (bytes, lengths, status codes) are identical to the reference's.
  * Plain pointers and sizes only.  All data pointers are DEVICE pointers (hipMalloc'ed, or
  * torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default
- * stream).  Calls enqueue work and return; they do not synchronise.  Return value: 0, or a
- * negative CSNAPPY_HIP_E_* code when the launch itself could not be made.
+ * stream).  Calls enqueue work and return; they do not synchronise -- with ONE exception: the first
+ * csnappy_hip_compress_batch of a process on a device first asks that device, on a stream of the
+ * library's own, whether its LDS serves the lanes of one instruction in ascending order (two small
+ * launches, a 4-byte copy and a wait of about a millisecond); make
+ * that first call outside a stream capture.  Return value: 0, or a negative CSNAPPY_HIP_E_* code
+ * when the launch itself could not be made.
  */
 #ifndef CSNAPPY_AMD_CSNAPPY_HIP_H_
 #define CSNAPPY_AMD_CSNAPPY_HIP_H_

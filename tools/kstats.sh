@@ -6,7 +6,7 @@ tag=$1; shift
 out=gpurun_out/kstats_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/g -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify-gib 0 "$@" > $out/bench.json 2> $out/bench.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/g -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --verify-gib 0 "$@" > $out/bench.json 2> $out/bench.err
 f=$(find $out/g -name '*kernel_stats.csv' | head -1)
 python3 - "$f" > gpurun_out/kstats_$tag.txt <<'PY'
 import csv, sys
