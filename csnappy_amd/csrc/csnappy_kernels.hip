@@ -558,6 +558,377 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	return nb;
 }
 
+/* ==========================================================================================
+ * The dense parser's step loop in ISA (round 6).  parse_lean's C++ below states the logic -- and
+ * still runs the steps this block leaves to it: sparse steps, the last steps of a fragment (a lane
+ * beyond the scan limit), fragments with a spill-over table, the other table placements, the
+ * ORD = false parsers.  This block is the same logic for the common case -- table in LDS indexed by
+ * dense ids, all 64 lanes in front of the scan limit -- written by hand as ONE loop:
+ *
+ *   12: FRONT   table read + returning add, check bit, candidate gather with the previous step's
+ *               record store behind it, flagged lanes, 16-byte comparison, stop / special masks,
+ *               next-stop table, the walk's plain hops
+ *   13: VISIT   the walk stands at a special lane (a flagged one, or a match of all 16 bytes that
+ *               may be longer): settled as parse_lean's visits() does, the walk goes on
+ *   14:         no copy in the whole step: the scan goes on behind its last probe
+ *   10: BACK    cursor, records (running maximum of the copies' ends by DPP), 11: the next step's
+ *               loads, commit; leaves at 19 when the next step is not one for this loop
+ *
+ * 239 instructions on the common path of round 5's compiled step, ~145 here.  The compiler's version
+ * spends the difference on boolean round trips (v_cndmask 0/1 + v_cmp for every ballot of a combined
+ * predicate), lane-mask tests in vector registers where v_cndmask takes the mask as it is, v_mbcnt,
+ * selects where the dummy table entry needs none, copies at the loop's head, back edge and around
+ * every visit, and s_nops where independent instructions fit.
+ *
+ * Wait states are spelled out (gfx940 family; the compiler's hazard recogniser does not look into
+ * inline asm): vector-written SGPR -> vector read: 2, -> v_readlane / v_writelane lane select: 4;
+ * vector-written VGPR -> DPP read: 2, -> v_readlane: 1.  A scalar instruction may read a
+ * vector-written SGPR at once.
+ *
+ * Registers are fixed (named as clobbers, or bound to register variables where C++ hands values in
+ * and out):
+ *   v40 mlen   v41 cl   v42 cand   v43 nx   v44 entry address   v45 its dword   v46 my 1   v47 my entry
+ *   v48 pos    v49 probes left per lane (32; lane 0: what is left of the scan)   v50 id   v51 record offset
+ *   v52-55 own 16 bytes   v56-57, v60-67 scratch   v58-59 the step's record
+ *   s[60:61] lanes with a bucket   s[62:63] flagged   s[64:65] stops   s[66:67] special   s[68:69] taken
+ *   s[70:71] candidate can match / inside a copy   s72-s79, s84-s91 scratch   s80 t   s81 lim0   s82 go
+ * ======================================================================================== */
+#define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
+	"1:\n\t"                                                                                                           \
+	"s_bitset1_b64 s[68:69], s80\n\t"                                                                                  \
+	"v_readlane_b32 s80, v43, s80\n\t"                                                                                 \
+	"s_nop 0\n\t"                                                                                                      \
+	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
+	"s_cbranch_scc1 1b\n\t"
+
+#define CSNAPPY_ISA_PREFIX16(d, a, b, c) /* d = equal leading bytes (0..16) of the strings whose XOR is d, a, b, c */  \
+	"v_ffbl_b32_e32 " d ", " d "\n\t"                                                                                  \
+	"v_ffbl_b32_e32 " a ", " a "\n\t"                                                                                  \
+	"v_ffbl_b32_e32 " b ", " b "\n\t"                                                                                  \
+	"v_ffbl_b32_e32 " c ", " c "\n\t"                                                                                  \
+	"v_add_u32_e64 " a ", " a ", 32 clamp\n\t"                                                                         \
+	"v_add_u32_e64 " c ", " c ", 32 clamp\n\t"                                                                         \
+	"v_min3_u32 " d ", " d ", " a ", 64\n\t"          /* equal low bits of bytes 0..7 (64: all) */                     \
+	"v_min3_u32 " b ", " b ", " c ", 64\n\t"          /* ... of bytes 8..15 */                                         \
+	"v_lshrrev_b32_e32 " a ", 6, " d "\n\t"                                                                            \
+	"v_mad_u32_u24 " d ", " a ", " b ", " d "\n\t"    /* + the high half when the low one is all equal */              \
+	"v_lshrrev_b32_e32 " d ", 3, " d "\n\t"
+
+#define CSNAPPY_DENSE_ISA                                                                                              \
+	"v_mov_b32_e32 v49, 32\n\t"                                                                                        \
+	"s_mov_b32 s83, m0\n\t"                            /* (m0 is the compiler's: given back at 19) */                  \
+	"s_branch 12f\n\t"                                                                                                 \
+	/* ================= BACK: the walk has left the step and took at least one copy ================= */            \
+	"10:\n\t"                                                                                                          \
+	"s_flbit_i32_b64 s72, s[68:69]\n\t"                                                                                \
+	"s_xor_b32 s72, s72, 63\n\t"                       /* the last copy's lane */                                      \
+	"v_mov_b32_e32 v66, %[nemit]\n\t"                  /* where the pending literal starts */                          \
+	"v_readlane_b32 s73, v41, s72\n\t"                 /* c: the lane behind the last copy */                          \
+	"v_add_u32_e32 v67, %[p0], v41\n\t"                /* where my copy ends */                                        \
+	"s_bcnt1_i32_b64 s78, s[68:69]\n\t"                                                                                \
+	"v_cndmask_b32_e64 v67, v66, v67, s[68:69]\n\t"                                                                    \
+	"s_add_u32 %[nemit], %[p0], s73\n\t"               /* next_emit: behind the last copy */                           \
+	"s_add_u32 s74, s73, 32\n\t"                                                                                       \
+	"v_max_u32_dpp v67, v67, v67 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_min_u32 s74, s74, 63\n\t"                       /* e: the last lane the step probes */                          \
+	"s_add_u32 s75, s73, -1\n\t"                       /* c - 1 */                                                     \
+	"v_max_u32_dpp v67, v67, v67 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_sub_u32 s76, s74, s75\n\t"                      /* probes of the scan behind the copy: e - c + 1 */             \
+	"s_cmp_ge_u32 s73, 64\n\t"                         /* the copy leaves the step: re-match probe next */             \
+	"v_max_u32_dpp v67, v67, v67 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_cselect_b32 s75, s75, s74\n\t"                  /* lane 0 of the next step */                                   \
+	"s_cselect_b32 %[q1], 0, s76\n\t"                                                                                  \
+	"v_max_u32_dpp v67, v67, v67 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_cselect_b32 s72, s72, s74\n\t"                  /* e_final: the last lane that is inserted */                   \
+	"s_mov_b64 vcc, s[68:69]\n\t"                                                                                      \
+	"v_max_u32_dpp v67, v67, v67 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
+	"v_mbcnt_lo_u32_b32 v56, vcc_lo, 0\n\t"                                                                            \
+	"v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t"          /* taken lanes below me */                                      \
+	"v_max_u32_dpp v67, v67, v67 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
+	"v_lshl_or_b32 v58, v42, 16, v48\n\t"              /* record: base | cand << 16 */                                 \
+	"v_add_u32_e32 v57, 1, v48\n\t"                                                                                    \
+	"v_mov_b32_dpp v66, v67 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */ \
+	"s_add_u32 %[p0], %[p0], s75\n\t"                  /* pz */                                                        \
+	"v_add_lshl_u32 v56, v56, %[nev], 3\n\t"           /* my record's byte offset */                                   \
+	"s_add_u32 %[nev], %[nev], s78\n\t"                                                                                \
+	"v_lshl_or_b32 v59, v66, 16, v40\n\t"              /* record: copy_len | lit_start << 16 */                        \
+	"v_cmp_lt_u32_e64 s[70:71], v57, v66\n\t"          /* strictly inside a copy: never inserted */                    \
+	"v_cndmask_b32_e64 v51, %[norec], v56, s[68:69]\n\t"                                                               \
+	/* ---- 11: the cursor is known: the next step's loads, then this step's commit ---- */                         \
+	"11:\n\t"                                                                                                          \
+	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
+	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */                          \
+	"v_add_u32_e32 v48, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"v_min_u32_e32 v57, %[safemax], v48\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	"global_load_dwordx4 v[52:55], v57, %[src]\n\t"                                                                    \
+	"v_lshlrev_b32_e32 v56, 1, v57\n\t"                                                                                \
+	"global_load_ushort v50, v56, %[ids]\n\t"                                                                          \
+	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
+	"ds_sub_u32 v45, v46\n\t"                          /* the adds are taken back */                                   \
+	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
+	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
+	"ds_write_b16 v44, v47\n\t"                        /* (of several with one slot the highest stays) */              \
+	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	"s_cmp_lt_u32 s82, 33\n\t"                                                                                         \
+	"s_cbranch_scc0 19f\n\t"                                                                                           \
+	/* ================= FRONT ================= */                                                                  \
+	"12:\n\t"                                                                                                          \
+	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
+	"v_lshlrev_b32_e32 v44, 1, v50\n\t"                /* my table entry (id 0: the dummy) */                          \
+	"ds_read_u16 v64, v44\n\t"                                                                                         \
+	"v_and_b32_e32 v45, 0xfffc, v44\n\t"               /* its dword */                                                 \
+	"v_lshlrev_b32_e32 v66, 4, v50\n\t"                /* bits 4:0 = 16 * (id & 1) */                                  \
+	"v_lshlrev_b32_e64 v46, v66, 1\n\t"                /* 1 in my half */                                              \
+	"ds_add_rtn_u32 v65, v45, v46\n\t"                 /* comes back with the lower lanes' ones in it */               \
+	"v_writelane_b32 v49, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */ \
+	"v_mul_lo_u32 v67, v52, %[mul]\n\t"                                                                                \
+	"v_bfe_u32 v67, v67, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	"v_cmp_ne_u32_e64 s[60:61], 0, v50\n\t"            /* lanes with a bucket */                                       \
+	"v_lshl_or_b32 v47, v67, 15, v48\n\t"              /* my entry, if I am inserted */                                \
+	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
+	"v_xor_b32_e32 v67, v64, v47\n\t"                                                                                  \
+	"v_and_b32_e32 v42, 0x7fff, v64\n\t"                                                                               \
+	"v_cmp_lt_u32_e32 vcc, v67, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_and_b64 s[70:71], vcc, s[60:61]\n\t"            /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v67, 0, v42, s[70:71]\n\t"                                                                      \
+	"global_load_dwordx4 v[60:63], v67, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 v51, v[58:59], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_bfe_u32 v65, v65, v66, 16\n\t"                  /* my half as the add found it */                               \
+	"v_cmp_ne_u32_e32 vcc, v65, v64\n\t"               /* not the entry: a lower lane has my slot */                   \
+	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes */                                             \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */                  \
+	"v_xor_b32_e32 v60, v60, v52\n\t"                                                                                  \
+	"v_xor_b32_e32 v61, v61, v53\n\t"                                                                                  \
+	"v_xor_b32_e32 v62, v62, v54\n\t"                                                                                  \
+	"v_xor_b32_e32 v63, v63, v55\n\t"                                                                                  \
+	CSNAPPY_ISA_PREFIX16("v60", "v61", "v62", "v63")                                                                   \
+	"v_cndmask_b32_e64 v40, 0, v60, s[70:71]\n\t"      /* lane-local match length, 0..16 */                            \
+	"v_cmp_lt_u32_e64 s[64:65], 3, v40\n\t"            /* matches */                                                   \
+	"v_cmp_eq_u32_e32 vcc, 16, v40\n\t"                /* may be longer */                                             \
+	"v_add_u32_e32 v41, %[lane], v40\n\t"              /* lane of the re-match probe behind my match */                \
+	"s_or_b64 s[64:65], s[64:65], s[62:63]\n\t"        /* stops of the chain: matches and flagged lanes */             \
+	"s_or_b64 s[66:67], vcc, s[62:63]\n\t"             /* ... that need a visit */                                     \
+	"v_lshrrev_b64 v[56:57], v41, s[64:65]\n\t"                                                                        \
+	"v_sub_u32_e32 v62, 63, v41\n\t"                   /* lanes left behind my match (negative: none) */               \
+	"v_ffbl_b32_e32 v57, v57\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v56, v56\n\t"                                                                                      \
+	"v_add_u32_e64 v57, v57, 32 clamp\n\t"                                                                             \
+	"v_min_i32_e32 v62, v62, v49\n\t"                  /* ... and probes */                                            \
+	"v_min3_u32 v56, v56, v57, 64\n\t"                 /* distance to the next stop */                                 \
+	"v_add_u32_e32 v63, v41, v56\n\t"                  /* its lane */                                                  \
+	"v_cmp_le_i32_e32 vcc, v56, v62\n\t"                                                                               \
+	"v_lshrrev_b64 v[60:61], v63, s[66:67]\n\t"                                                                        \
+	"v_and_b32_e32 v60, 1, v60\n\t"                                                                                    \
+	"v_lshl_or_b32 v64, v60, 7, v63\n\t"               /* lane | 128: a special one */                                 \
+	"v_cndmask_b32_e32 v43, 64, v64, vcc\n\t"          /* next stop of the chain if my match is taken (64: none here) */ \
+	"s_mov_b64 s[68:69], 0\n\t"                                                                                        \
+	"v_readlane_b32 s80, v43, 0\n\t"                   /* the walk: lane 0 holds the first stop */                     \
+	"s_nop 0\n\t"                                                                                                      \
+	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
+	"s_cbranch_scc0 13f\n\t"                           /* none, or a special lane */                                   \
+	CSNAPPY_ISA_HOPS                                                                                                   \
+	"s_cmp_eq_u32 s80, 64\n\t"                         /* the walk left the step */                                    \
+	"s_cbranch_scc1 10b\n\t"                                                                                           \
+	/* ================= VISIT: t >= 128, lane t & 63 is special (parse_lean's visits()) ================= */       \
+	"13:\n\t"                                                                                                          \
+	"s_cmp_lt_u32 s80, 128\n\t"                                                                                        \
+	"s_cbranch_scc1 14f\n\t"                           /* 64 / 65: the walk left the step */                           \
+	"s_and_b32 s73, s80, 63\n\t"                       /* i */                                                         \
+	"s_mov_b32 m0, s73\n\t"                            /* (v_writelane takes one SGPR: its lane select goes through m0) */ \
+	"v_readlane_b32 s74, v40, s73\n\t"                 /* L: its lane-local match length */                            \
+	"s_bitcmp1_b64 s[62:63], s73\n\t"                                                                                  \
+	"s_cbranch_scc0 30f\n\t"                           /* not flagged: a match of 16 bytes that may be longer */       \
+	/* ---- a flagged lane: its candidate is the latest position inserted for its slot -- the highest lane    \
+	 * below it with the same slot that this step inserts (not strictly inside a copy of the chain), whose   \
+	 * bytes are that lane's own 16 bytes -- else the table entry it compared with ---- */                          \
+	"v_readlane_b32 s75, v50, s73\n\t"                 /* its slot */                                                  \
+	"s_bfm_b64 s[84:85], s73, 0\n\t"                   /* lanes below i */                                             \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_cmp_eq_u32_e32 vcc, s75, v50\n\t"                                                                               \
+	"s_and_b64 s[86:87], vcc, s[60:61]\n\t"                                                                            \
+	"s_and_b64 s[86:87], s[86:87], s[84:85]\n\t"       /* same: lanes below i with its slot */                         \
+	"s_cmp_eq_u64 s[86:87], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 24f\n\t"                                                                                           \
+	"s_cmp_eq_u64 s[68:69], 0\n\t"                     /* no copy taken yet: every lane below was inserted */          \
+	"s_cbranch_scc1 23f\n\t"                                                                                           \
+	/* the highest of `same` tested on the scalar unit: inside the nearest taken copy below it? */                  \
+	"s_flbit_i32_b64 s76, s[86:87]\n\t"                                                                                \
+	"s_xor_b32 s76, s76, 63\n\t"                       /* jh */                                                        \
+	"s_bfm_b64 s[88:89], s76, 0\n\t"                                                                                   \
+	"s_and_b64 s[88:89], s[88:89], s[68:69]\n\t"       /* taken lanes below jh */                                      \
+	"s_cmp_eq_u64 s[88:89], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 23f\n\t"                                                                                           \
+	"s_flbit_i32_b64 s77, s[88:89]\n\t"                                                                                \
+	"s_xor_b32 s77, s77, 63\n\t"                                                                                       \
+	"v_readlane_b32 s77, v41, s77\n\t"                 /* where the nearest of them ends */                            \
+	"s_add_u32 s78, s76, 1\n\t"                                                                                        \
+	"s_cmp_lt_u32 s78, s77\n\t"                                                                                        \
+	"s_cbranch_scc0 23f\n\t"                           /* jh was inserted */                                           \
+	/* it was not: settle all of `same` at once -- the end of the nearest taken copy below every lane is the  \
+	 * running maximum of the taken lanes' ends (they grow along the chain) */                                      \
+	"v_cndmask_b32_e64 v64, 0, v41, s[68:69]\n\t"                                                                      \
+	"v_add_u32_e32 v66, 1, %[lane]\n\t"                                                                                \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v64, v64, v64 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
+	"v_mov_b32_e32 v65, 0\n\t"                                                                                         \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_mov_b32_dpp v65, v64 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                                 \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_cmp_lt_u32_e32 vcc, v66, v65\n\t"               /* lane + 1 < that end: never inserted */                       \
+	"s_andn2_b64 s[86:87], s[86:87], vcc\n\t"                                                                          \
+	"s_cmp_eq_u64 s[86:87], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 24f\n\t"                                                                                           \
+	"23:\n\t"                                          /* j: the highest lane of `same`; its bytes against everyone's */ \
+	"s_flbit_i32_b64 s76, s[86:87]\n\t"                                                                                \
+	"s_xor_b32 s76, s76, 63\n\t"                                                                                       \
+	"v_readlane_b32 s88, v52, s76\n\t"                                                                                 \
+	"v_readlane_b32 s89, v53, s76\n\t"                                                                                 \
+	"v_readlane_b32 s90, v54, s76\n\t"                                                                                 \
+	"v_readlane_b32 s91, v55, s76\n\t"                                                                                 \
+	"s_add_u32 s77, %[p0], s76\n\t"                    /* its position */                                              \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_xor_b32_e32 v60, s88, v52\n\t"                                                                                  \
+	"v_xor_b32_e32 v61, s89, v53\n\t"                                                                                  \
+	"v_xor_b32_e32 v62, s90, v54\n\t"                                                                                  \
+	"v_xor_b32_e32 v63, s91, v55\n\t"                                                                                  \
+	CSNAPPY_ISA_PREFIX16("v60", "v61", "v62", "v63")                                                                   \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_readlane_b32 s74, v60, s73\n\t"                 /* L: lane i's match length against it */                       \
+	"v_writelane_b32 v42, s77, m0\n\t"                 /* and its candidate */                                         \
+	"24:\n\t"                                                                                                          \
+	"s_cmp_lt_u32 s74, 4\n\t"                                                                                          \
+	"s_cbranch_scc0 30f\n\t"                                                                                           \
+	/* ---- no match at the flagged lane: on to the next stop of the current window ---- */                         \
+	"s_mov_b32 s77, s81\n\t"                           /* probes left: of the scan in progress ... */                  \
+	"s_cmp_eq_u64 s[68:69], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 25f\n\t"                                                                                           \
+	"s_flbit_i32_b64 s77, s[68:69]\n\t"                                                                                \
+	"s_xor_b32 s77, s77, 63\n\t"                                                                                       \
+	"v_readlane_b32 s77, v41, s77\n\t"                                                                                 \
+	"s_add_u32 s77, s77, 32\n\t"                       /* ... or the 33 behind the last copy */                        \
+	"25:\n\t"                                                                                                          \
+	"s_bitset1_b64 s[84:85], s73\n\t"                  /* lanes up to i */                                             \
+	"s_andn2_b64 s[84:85], s[64:65], s[84:85]\n\t"     /* stops behind i */                                            \
+	"s_ff1_i32_b64 s78, s[84:85]\n\t"                                                                                  \
+	"s_mov_b32 s80, 65\n\t"                                                                                            \
+	"s_cmp_lt_i32 s78, 0\n\t"                                                                                          \
+	"s_cbranch_scc1 14f\n\t"                           /* none */                                                      \
+	"s_cmp_gt_u32 s78, s77\n\t"                                                                                        \
+	"s_cbranch_scc1 14f\n\t"                           /* beyond the window */                                         \
+	"s_bitcmp1_b64 s[66:67], s78\n\t"                                                                                  \
+	"s_cselect_b32 s79, 128, 0\n\t"                                                                                    \
+	"s_or_b32 s80, s78, s79\n\t"                                                                                       \
+	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
+	"s_cbranch_scc0 13b\n\t"                                                                                           \
+	CSNAPPY_ISA_HOPS                                                                                                   \
+	"s_branch 13b\n\t"                                                                                                 \
+	/* ---- a match of L >= 4 bytes at lane i; L == 16 may be longer: FindMatchLength beyond the lane-local  \
+	 * 16 bytes, 512 bytes a round (csnappy_compress.c:252-295), never reading past the fragment ---- */            \
+	"30:\n\t"                                                                                                          \
+	"s_cmp_eq_u32 s74, 16\n\t"                                                                                         \
+	"s_cbranch_scc0 35f\n\t"                                                                                           \
+	"s_add_u32 s76, %[p0], s73\n\t"                                                                                    \
+	"s_add_u32 s76, s76, 16\n\t"                       /* mb = base + 16 */                                            \
+	"s_cmp_lt_u32 s76, %[n]\n\t"                                                                                       \
+	"s_cbranch_scc0 35f\n\t"                                                                                           \
+	"v_readlane_b32 s77, v42, s73\n\t"                                                                                 \
+	"s_sub_u32 s78, %[n], s76\n\t"                     /* lim: bytes left behind mb */                                 \
+	"s_mov_b32 s79, 0\n\t"                             /* done */                                                      \
+	"v_lshlrev_b32_e32 v64, 3, %[lane]\n\t"                                                                            \
+	"s_add_u32 s77, s77, 16\n\t"                       /* ma = cand + 16 */                                            \
+	"31:\n\t"                                                                                                          \
+	"v_add_u32_e32 v65, s79, v64\n\t"                  /* o = done + 8 * lane */                                       \
+	"v_sub_u32_e32 v66, s78, v65\n\t"                                                                                  \
+	"v_cmp_gt_u32_e64 s[84:85], s78, v65\n\t"          /* o < lim: my eight bytes begin inside the fragment */         \
+	"v_min_u32_e32 v66, 8, v66\n\t"                    /* r: how many of them are inside */                            \
+	"v_sub_u32_e32 v67, 8, v66\n\t"                    /* back: read the eight bytes that END at the fragment's end */ \
+	"v_sub_u32_e32 v60, v65, v67\n\t"                                                                                  \
+	"v_cndmask_b32_e64 v60, 0, v60, s[84:85]\n\t"                                                                      \
+	"v_add_u32_e32 v61, s77, v60\n\t"                                                                                  \
+	"v_add_u32_e32 v60, s76, v60\n\t"                                                                                  \
+	"global_load_dwordx2 v[56:57], v61, %[src]\n\t"                                                                    \
+	"global_load_dwordx2 v[62:63], v60, %[src]\n\t"                                                                    \
+	"v_lshlrev_b32_e32 v67, 3, v67\n\t"                                                                                \
+	"v_add_u32_e32 v61, 8, v65\n\t"                                                                                    \
+	"s_waitcnt vmcnt(0)\n\t"                                                                                           \
+	"v_xor_b32_e32 v56, v56, v62\n\t"                                                                                  \
+	"v_xor_b32_e32 v57, v57, v63\n\t"                                                                                  \
+	"v_lshrrev_b64 v[56:57], v67, v[56:57]\n\t"        /* drop the bytes in front of o */                              \
+	"v_cmp_le_u32_e32 vcc, s78, v61\n\t"               /* o + 8 >= lim: the fragment ends in my bytes */               \
+	"v_ffbl_b32_e32 v60, v56\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v62, v57\n\t"                                                                                      \
+	"v_add_u32_e64 v62, v62, 32 clamp\n\t"                                                                             \
+	"v_min3_u32 v60, v60, v62, 64\n\t"                                                                                 \
+	"v_lshrrev_b32_e32 v60, 3, v60\n\t"                /* equal bytes (8: all) */                                      \
+	"v_min_u32_e32 v60, v60, v66\n\t"                                                                                  \
+	"v_cndmask_b32_e64 v60, 0, v60, s[84:85]\n\t"      /* m8 (lanes beyond the fragment: 0) */                         \
+	"v_cmp_gt_u32_e64 s[86:87], 8, v60\n\t"            /* the match ends in my bytes */                                \
+	"s_or_b64 s[86:87], s[86:87], vcc\n\t"                                                                             \
+	"s_cmp_lg_u64 s[86:87], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 32f\n\t"                                                                                           \
+	"s_add_u32 s79, s79, 512\n\t"                                                                                      \
+	"s_branch 31b\n\t"                                                                                                 \
+	"32:\n\t"                                                                                                          \
+	"s_ff1_i32_b64 s88, s[86:87]\n\t"                  /* the first lane it ends in */                                 \
+	"v_readlane_b32 s89, v60, s88\n\t"                                                                                 \
+	"s_lshl_b32 s88, s88, 3\n\t"                                                                                       \
+	"s_add_u32 s79, s79, s88\n\t"                                                                                      \
+	"s_add_u32 s79, s79, s89\n\t"                                                                                      \
+	"s_add_u32 s74, s79, 16\n\t"                       /* L */                                                         \
+	"35:\n\t"                                          /* the copy is taken */                                         \
+	"s_add_u32 s75, s73, s74\n\t"                      /* the lane behind it */                                        \
+	"v_writelane_b32 v40, s74, m0\n\t"                                                                                 \
+	"v_writelane_b32 v41, s75, m0\n\t"                                                                                 \
+	"s_bitset1_b64 s[68:69], s73\n\t"                                                                                  \
+	/* the next stop behind it, on the scalar unit (64: the re-match probe falls outside the step; 65: none  \
+	 * of the 33 probes behind the copy is a stop) */                                                               \
+	"s_mov_b32 s80, 64\n\t"                                                                                            \
+	"s_cmp_ge_u32 s75, 64\n\t"                                                                                         \
+	"s_cbranch_scc1 14f\n\t"                                                                                           \
+	"s_lshr_b64 s[84:85], s[64:65], s75\n\t"                                                                           \
+	"s_ff1_i32_b64 s76, s[84:85]\n\t"                                                                                  \
+	"s_mov_b32 s80, 65\n\t"                                                                                            \
+	"s_cmp_gt_u32 s76, 32\n\t"                         /* (none: -1) */                                                \
+	"s_cbranch_scc1 14f\n\t"                                                                                           \
+	"s_add_u32 s76, s76, s75\n\t"                                                                                      \
+	"s_cmp_gt_u32 s76, 63\n\t"                                                                                         \
+	"s_cbranch_scc1 14f\n\t"                                                                                           \
+	"s_bitcmp1_b64 s[66:67], s76\n\t"                                                                                  \
+	"s_cselect_b32 s77, 128, 0\n\t"                                                                                    \
+	"s_or_b32 s80, s76, s77\n\t"                                                                                       \
+	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
+	"s_cbranch_scc0 13b\n\t"                                                                                           \
+	CSNAPPY_ISA_HOPS                                                                                                   \
+	"s_branch 13b\n\t"                                                                                                 \
+	/* ================= 14: the walk has left the step ================= */                                        \
+	"14:\n\t"                                                                                                          \
+	"s_cmp_lg_u64 s[68:69], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 10b\n\t"                                                                                           \
+	/* no copy in the whole step: the scan goes on behind its last probe (csnappy_compress.c:535-552);       \
+	 * nothing to record; every lane up to that probe is inserted */                                                \
+	"s_min_u32 s72, s81, 63\n\t"                       /* e_final */                                                   \
+	"v_mov_b32_e32 v58, 0\n\t"                                                                                         \
+	"v_mov_b32_e32 v59, 0\n\t"                                                                                         \
+	"v_mov_b32_e32 v51, %[norec]\n\t"                                                                                  \
+	"s_add_u32 %[q1], %[q1], s72\n\t"                                                                                  \
+	"s_add_u32 %[p0], %[p0], s72\n\t"                                                                                  \
+	"s_mov_b64 s[70:71], 0\n\t"                                                                                        \
+	"s_branch 11b\n\t"                                                                                                 \
+	"19:\n\t"                                                                                                          \
+	"s_mov_b32 m0, s83\n\t"
+
 template <int TAB, bool SPILL, bool PROF = false, bool ORD = true>
 DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 {
@@ -840,27 +1211,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			}
 		};
 
-		/* ==================================================================================
-		 * The fast path (round 6): the common case of a dense step -- table in LDS by dense ids, no
-		 * spill-over, all 64 lanes in front of the scan limit -- written by hand, two asm blocks:
-		 *   FRONT  table read + returning add, check bit, candidate gather, the previous step's record
-		 *          store behind it, flagged lanes, 16-byte comparison, stop / special masks, next-stop
-		 *          table, the walk's plain hops                       (what the C++ below does up to
-		 *          CSNAPPY_HOPS; same values in the same variables, so visits() serves both)
-		 *   BACK   cursor, the next step's loads, records, commit     (the C++ behind visits())
-		 * and a loop of [BACK of step k; FRONT of step k + 1] as ONE block, so that the loads BACK
-		 * requests are waited for inside the block that issued them.  Between the blocks C++ only tests
-		 * for a special lane (visits()) and for a step without any copy (settled in a few lines of C++).
-		 * 239 -> ~155 instructions per step; the compiler's version spends the difference on boolean
-		 * round trips (v_cndmask 0/1 + v_cmp for every ballot of a combined predicate), 64-bit lane-mask
-		 * tests in vector registers where v_cndmask takes the mask as it is, v_mbcnt, selects where the
-		 * dummy table entry needs none, a dozen copies at the loop's head and back edge, and s_nops where
-		 * independent instructions fit.
-		 * Wait states are spelled out (gfx940 family): vector-written SGPR -> vector read: 2; -> v_readlane
-		 * lane select: 4; vector-written VGPR -> DPP read: 2, -> v_readlane: 1.  Scratch registers are fixed
-		 * (v52-v67, s70-s79, vcc) and named as clobbers or through register variables; the dense kernel
-		 * has 67 VGPRs anyway (its prologue).
-		 * ================================================================================== */
+		/* the step loop in ISA for the common case (CSNAPPY_DENSE_ISA above) */
 		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
 		/* a step is fast-eligible when it is dense (q1 <= 32) and pz + 64 < ip_limit: every lane is valid,
 		 * and so is every lane's p0 + lane + 16 < n */
@@ -869,221 +1220,34 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 
 		while (!fin && ++guard <= n) {
 			if constexpr (FAST) if (q1 <= 32 && pz < limit64) {
-				/* (all of this block's variables are the fast path's own; the general step below does
-				 * not see them) */
-				register uint32_t x0 asm("v52"), x1 asm("v53"), x2 asm("v54"), x3 asm("v55");
-				register uint32_t px asm("v58"), py asm("v59");
-				uint32_t a16, a32, one, mine, go = 0;
-				uint32_t k32 = 32, thr = lane == 0 ? 0u : 0x8000u;
-				const uint32_t shm1 = shift - 1, mul = kHashMul, safemax = n - 16;
-				px = prec.x;
-				py = prec.y;
-#define CSNAPPY_FRONT_TEXT                                                                                             \
-	"s_sub_u32 %[lim0], 33, %[q1]\n\t"                 /* probes the scan in progress has left */                      \
-	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
-	"v_lshlrev_b32_e32 %[a16], 1, %[sid]\n\t"          /* my table entry (id 0: the dummy) */                          \
-	"ds_read_u16 v64, %[a16]\n\t"                                                                                      \
-	"v_and_b32_e32 %[a32], 0xfffc, %[a16]\n\t"         /* its dword */                                                 \
-	"v_lshlrev_b32_e32 v66, 4, %[sid]\n\t"             /* bits 4:0 = 16 * (id & 1) */                                  \
-	"v_lshlrev_b32_e64 %[one], v66, 1\n\t"             /* 1 in my half */                                              \
-	"ds_add_rtn_u32 v65, %[a32], %[one]\n\t"           /* comes back with the lower lanes' ones in it */               \
-	"v_writelane_b32 %[k32], %[lim0], 0\n\t"           /* lane 0 searches what is left of the scan, the others 33 probes */ \
-	"v_mul_lo_u32 v67, %[me0], %[mul]\n\t"                                                                             \
-	"v_bfe_u32 v67, v67, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
-	"v_cmp_ne_u32_e64 %[tmask], 0, %[sid]\n\t"         /* lanes with a bucket */                                       \
-	"v_lshl_or_b32 %[mine], v67, 15, %[pos]\n\t"       /* my entry, if I am inserted */                                \
-	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
-	"v_xor_b32_e32 v67, v64, %[mine]\n\t"                                                                              \
-	"v_and_b32_e32 %[cand], 0x7fff, v64\n\t"                                                                           \
-	"v_cmp_lt_u32_e32 vcc, v67, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
-	"s_and_b64 s[70:71], vcc, %[tmask]\n\t"            /* the candidate can match at all */                            \
-	"v_cndmask_b32_e64 v67, 0, %[cand], s[70:71]\n\t"                                                                  \
-	"global_load_dwordx4 v[60:63], v67, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
-	"global_store_dwordx2 %[precoff], v[58:59], %[R]\n\t" /* the previous step's records, behind the gather */         \
-	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
-	"v_bfe_u32 v65, v65, v66, 16\n\t"                  /* my half as the add found it */                               \
-	"v_cmp_ne_u32_e32 vcc, v65, v64\n\t"               /* not the entry: a lower lane has my slot */                   \
-	"s_and_b64 %[cmask], vcc, %[tmask]\n\t"            /* flagged lanes */                                             \
-	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */                  \
-	"v_xor_b32_e32 v60, v60, %[me0]\n\t"                                                                               \
-	"v_xor_b32_e32 v61, v61, %[me1]\n\t"                                                                               \
-	"v_xor_b32_e32 v62, v62, %[me2]\n\t"                                                                               \
-	"v_xor_b32_e32 v63, v63, %[me3]\n\t"                                                                               \
-	"v_ffbl_b32_e32 v60, v60\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v61, v61\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v62, v62\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v63, v63\n\t"                                                                                      \
-	"v_add_u32_e64 v61, v61, 32 clamp\n\t"                                                                             \
-	"v_add_u32_e64 v63, v63, 32 clamp\n\t"                                                                             \
-	"v_min3_u32 v60, v60, v61, 64\n\t"                 /* equal low bits of bytes 0..7 (64: all) */                    \
-	"v_min3_u32 v62, v62, v63, 64\n\t"                 /* ... of bytes 8..15 */                                        \
-	"v_lshrrev_b32_e32 v61, 6, v60\n\t"                                                                                \
-	"v_mad_u32_u24 v60, v61, v62, v60\n\t"             /* + the high half when the low one is all equal */             \
-	"v_lshrrev_b32_e32 v60, 3, v60\n\t"                                                                                \
-	"v_cndmask_b32_e64 %[mlen], 0, v60, s[70:71]\n\t"  /* lane-local match length, 0..16 */                            \
-	"v_cmp_lt_u32_e64 %[stop], 3, %[mlen]\n\t"         /* matches */                                                   \
-	"v_cmp_eq_u32_e32 vcc, 16, %[mlen]\n\t"            /* may be longer */                                             \
-	"v_add_u32_e32 %[cl], %[lane], %[mlen]\n\t"        /* lane of the re-match probe behind my match */                \
-	"s_or_b64 %[stop], %[stop], %[cmask]\n\t"          /* stops of the chain: matches and flagged lanes */             \
-	"s_or_b64 %[special], vcc, %[cmask]\n\t"           /* ... that need a visit */                                     \
-	"v_lshrrev_b64 v[56:57], %[cl], %[stop]\n\t"                                                                       \
-	"v_sub_u32_e32 v62, 63, %[cl]\n\t"                 /* lanes left behind my match (negative: none) */               \
-	"v_ffbl_b32_e32 v57, v57\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v56, v56\n\t"                                                                                      \
-	"v_add_u32_e64 v57, v57, 32 clamp\n\t"                                                                             \
-	"v_min_i32_e32 v62, v62, %[k32]\n\t"               /* ... and probes */                                            \
-	"v_min3_u32 v56, v56, v57, 64\n\t"                 /* distance to the next stop */                                 \
-	"v_add_u32_e32 v63, %[cl], v56\n\t"                /* its lane */                                                  \
-	"v_cmp_le_i32_e32 vcc, v56, v62\n\t"                                                                               \
-	"v_lshrrev_b64 v[60:61], v63, %[special]\n\t"                                                                      \
-	"v_and_b32_e32 v60, 1, v60\n\t"                                                                                    \
-	"v_lshl_or_b32 v64, v60, 7, v63\n\t"               /* lane | 128: a special one */                                 \
-	"v_cndmask_b32_e32 %[nx], 64, v64, vcc\n\t"        /* next stop of the chain if my match is taken (64: none here) */ \
-	"s_mov_b64 %[taken], 0\n\t"                                                                                        \
-	"v_readlane_b32 %[t], %[nx], 0\n\t"                /* the walk: lane 0 holds the first stop */                     \
-	"s_nop 0\n\t"                                                                                                      \
-	"s_cmp_lt_u32 %[t], 64\n\t"                                                                                        \
-	"s_cbranch_scc0 9f\n\t"                          /* none, or a special lane: C++ (taken == 0) */                 \
-	"1:\n\t"                                                                                                           \
-	"s_bitset1_b64 %[taken], %[t]\n\t"                                                                                 \
-	"v_readlane_b32 %[t], %[nx], %[t]\n\t"                                                                             \
-	"s_nop 0\n\t"                                                                                                      \
-	"s_cmp_lt_u32 %[t], 64\n\t"                                                                                        \
-	"s_cbranch_scc1 1b\n\t"
-#define CSNAPPY_FAST_CLOBBERS                                                                                          \
-	"v56", "v57", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "s70", "s71", "s72", "s73", "s74", "s75",  \
-		"s76", "s77", "s78", "s79", "vcc", "scc", "memory"
-				/* FRONT of the first fast step (its loads came from place(): the compiler has waited for them) */
-				asm volatile(CSNAPPY_FRONT_TEXT "9:\n\t"
-					     : [mlen] "=&v"(mlen), [cl] "=&v"(cl), [cand] "=&v"(cand), [nx] "=&v"(nx), [a16] "=&v"(a16),
-					       [a32] "=&v"(a32), [one] "=&v"(one), [mine] "=&v"(mine), [tmask] "=&s"(tmask),
-					       [cmask] "=&s"(cmask), [stop] "=&s"(stopmask), [special] "=&s"(special),
-					       [taken] "=&s"(taken), [t] "=&s"(t), [lim0] "=&s"(lim0), [k32] "+v"(k32)
-					     : [me0] "v"(raw0), [me1] "v"(raw1), [me2] "v"(raw2), [me3] "v"(raw3), [sid] "v"(sid),
-					       [pos] "v"(pos), [q1] "s"(q1), [precoff] "v"(prec_off), "v"(px), "v"(py), [src] "s"(src),
-					       [R] "s"(R), [shm1] "s"(shm1), [mul] "s"(mul), [thr] "v"(thr), [lane] "v"(lane)
-					     : CSNAPPY_FAST_CLOBBERS);
-				me0 = raw0;
-				me1 = raw1;
-				me2 = raw2;
-				me3 = raw3;
-				slot = sid;
-				ulim = 64;
-				for (;;) {
-					p0 = pz;
-					if (__builtin_expect(t >= 128, 0))
-						visits();
-					/* (every scalar operand of the block below has a value on either path: an undefined one
-					 * reaches the block as a vector register, which it cannot take) */
-					uint32_t sidn = sid, posn = pos, offn = prec_off, nemit = next_emit;
-					go = 99;
-					if (__builtin_expect(taken == 0, 0)) {
-						/* no copy in this step: the scan goes on behind its last probe (:535-552); nothing
-						 * to record; every lane up to that probe is inserted */
-						const uint32_t e = min(lim0, 63u);
-						q1 += e;
-						pz += e;
-						prec = make_uint2(0, 0);
-						prec_off = no_rec_off;
-						(void)atomicSub(&tab32[slot >> 1], 1u << ((slot & 1u) << 4));
-						wave_lds_fence();
-						if (lane <= e)
-							tab[slot] = (uint16_t)mine;
-						wave_lds_fence();
-					} else {
-					/* BACK of this step, FRONT of the next, and round again for as long as the walk meets
-					 * nothing special.  Leaves with go >= 33 behind a BACK (the next step is not for the
-					 * fast path), else behind a FRONT whose walk stands at a special lane (t >= 128) or
-					 * found no first stop (taken == 0). */
-					asm volatile(
-						"0:\n\t"
-						"s_flbit_i32_b64 s72, %[taken]\n\t"
-						"s_xor_b32 s72, s72, 63\n\t"                     /* the last copy's lane */
-						"v_mov_b32_e32 v66, %[nemit]\n\t"                /* where the pending literal starts */
-						"v_readlane_b32 s73, %[cl], s72\n\t"             /* c: the lane behind the last copy */
-						"v_add_u32_e32 v67, %[p0], %[cl]\n\t"            /* where my copy ends */
-						"s_bcnt1_i32_b64 s78, %[taken]\n\t"
-						"v_cndmask_b32_e64 v67, v66, v67, %[taken]\n\t"
-						"s_add_u32 %[nemit], %[p0], s73\n\t"             /* next_emit: behind the last copy */
-						"s_add_u32 s74, s73, 32\n\t"
-						"v_max_u32_dpp v67, v67, v67 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-						"s_min_u32 s74, s74, 63\n\t"                     /* e: the last lane the step probes */
-						"s_add_u32 s75, s73, -1\n\t"                     /* c - 1 */
-						"v_max_u32_dpp v67, v67, v67 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-						"s_sub_u32 s76, s74, s75\n\t"                    /* probes of the scan behind the copy: e - c + 1 */
-						"s_cmp_ge_u32 s73, 64\n\t"                       /* the copy leaves the step: re-match probe next */
-						"v_max_u32_dpp v67, v67, v67 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-						"s_cselect_b32 s75, s75, s74\n\t"                /* lane 0 of the next step */
-						"s_cselect_b32 %[q1], 0, s76\n\t"
-						"v_max_u32_dpp v67, v67, v67 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-						"s_cselect_b32 s72, s72, s74\n\t"                /* e_final: the last lane that is inserted */
-						"s_mov_b64 vcc, %[taken]\n\t"
-						"v_max_u32_dpp v67, v67, v67 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-						"v_mbcnt_lo_u32_b32 v56, vcc_lo, 0\n\t"
-						"v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t"        /* taken lanes below me */
-						"v_max_u32_dpp v67, v67, v67 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-						"v_lshl_or_b32 v58, %[cand], 16, %[pos]\n\t"     /* record: base | cand << 16 */
-						"v_add_u32_e32 v57, 1, %[pos]\n\t"
-						"v_mov_b32_dpp v66, v67 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */
-						"s_add_u32 %[p0], %[p0], s75\n\t"                /* pz */
-						"v_add_lshl_u32 v56, v56, %[nev], 3\n\t"         /* my record's byte offset */
-						"s_add_u32 %[nev], %[nev], s78\n\t"
-						"v_lshl_or_b32 v59, v66, 16, %[mlen]\n\t"        /* record: copy_len | lit_start << 16 */
-						"v_cmp_lt_u32_e64 s[70:71], v57, v66\n\t"        /* strictly inside a copy: never inserted */
-						"v_cndmask_b32_e64 %[precoff], %[norec], v56, %[taken]\n\t"
-						"s_cmp_lt_u32 %[p0], %[limit64]\n\t"
-						"s_cselect_b32 %[go], %[q1], 99\n\t"             /* next step fast too: < 33 */
-						"v_add_u32_e32 %[pos], %[p0], %[lane]\n\t"       /* the next step's positions */
-						"v_min_u32_e32 v57, %[safemax], %[pos]\n\t"      /* (clamped: harmless loads when the fast path ends here) */
-						"global_load_dwordx4 v[52:55], v57, %[src]\n\t"
-						"v_lshlrev_b32_e32 v56, 1, v57\n\t"
-						"global_load_ushort %[sid], v56, %[ids]\n\t"
-						"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"         /* lanes up to e_final */
-						"ds_sub_u32 %[a32], %[one]\n\t"                  /* the adds are taken back */
-						"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"        /* inserted lanes */
-						"s_mov_b64 exec, s[70:71]\n\t"
-						"ds_write_b16 %[a16], %[mine]\n\t"               /* (of several with one slot the highest stays) */
-						"s_mov_b64 exec, -1\n\t"
-						"s_cmp_lt_u32 %[go], 33\n\t"
-						"s_cbranch_scc0 9f\n\t"
-						CSNAPPY_FRONT_TEXT
-						"s_cmp_eq_u32 %[t], 64\n\t"                   /* the walk left the step: its BACK (else a special lane: C++) */
-						"s_cbranch_scc1 0b\n\t"
-						"9:\n\t"
-						: [mlen] "+v"(mlen), [cl] "+v"(cl), [cand] "+v"(cand), [nx] "=&v"(nx), [a16] "+v"(a16),
-						  [a32] "+v"(a32), [one] "+v"(one), [mine] "+v"(mine), [tmask] "=&s"(tmask),
-						  [cmask] "=&s"(cmask), [stop] "=&s"(stopmask), [special] "=&s"(special),
-						  [taken] "+s"(taken), [t] "=&s"(t), [lim0] "=&s"(lim0), [k32] "+v"(k32),
-						  [me0] "=&v"(x0), [me1] "=&v"(x1), [me2] "=&v"(x2), [me3] "=&v"(x3), [sid] "=&v"(sidn),
-						  [pos] "+v"(posn), [precoff] "=&v"(offn), "=&v"(px), "=&v"(py), [p0] "+s"(pz), [q1] "+s"(q1),
-						  [nemit] "+s"(nemit), [nev] "+s"(nev), [go] "=&s"(go)
-						: [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shm1), [mul] "s"(mul), [thr] "v"(thr),
-						  [lane] "v"(lane), [norec] "v"(no_rec_off), [limit64] "s"(limit64), [safemax] "s"(safemax)
-						: CSNAPPY_FAST_CLOBBERS);
-					next_emit = nemit;
-					pos = posn;
-					prec_off = offn;
-					if (go >= 33) {
-						/* the fast path ends here: the loads BACK requested are still on their way */
-						asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(sidn));
-						prec = make_uint2(px, py);
-					}
-					}
-					if (go >= 33) {
-						fin = pz + 1 >= ip_limit;
-						place();
-						break;
-					}
-					me0 = x0;
-					me1 = x1;
-					me2 = x2;
-					me3 = x3;
-					slot = sid = sidn;
-				}
+				/* the values C++ hands over, in the registers the block keeps them in: the step's own
+				 * bytes, id and position (place() requested them), the pending record */
+				register uint32_t x0 asm("v52") = raw0, x1 asm("v53") = raw1, x2 asm("v54") = raw2, x3 asm("v55") = raw3;
+				register uint32_t vsid asm("v50") = sid, vpos asm("v48") = pos;
+				register uint32_t px asm("v58") = prec.x, py asm("v59") = prec.y, poff asm("v51") = prec_off;
+				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
+				uint32_t nemit = next_emit;
+				asm volatile(CSNAPPY_DENSE_ISA
+					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0), "+v"(x1),
+					       "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					     : [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shift - 1), [mul] "s"(kHashMul),
+					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n), [lane] "v"(lane), [thr] "v"(thr),
+					       [norec] "v"(no_rec_off)
+					     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v49", "v56", "v57", "v60", "v61",
+					       "v62", "v63", "v64", "v65", "v66", "v67", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+					       "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc",
+					       "scc", "memory");
+				/* (the loads its last step requested are still on their way: clamped addresses, nobody
+				 * wants them) */
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
+				next_emit = nemit;
+				prec = make_uint2(px, py);
+				prec_off = poff;
+				fin = pz + 1 >= ip_limit;
+				place();
 				continue;
 			}
-#undef CSNAPPY_FRONT_TEXT
-#undef CSNAPPY_FAST_CLOBBERS
 			tick(0); /* (rest of the previous step: commit) */
 			if (PROF) {
 				asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2), "+v"(raw3), "+v"(sid));
