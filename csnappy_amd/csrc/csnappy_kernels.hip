@@ -586,17 +586,20 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  * vector-written SGPR at once.
  *
  * Registers are fixed (named as clobbers, or bound to register variables where C++ hands values in
- * and out):
- *   v40 mlen   v41 cl   v42 cand   v43 nx   v44 entry address   v45 its dword   v46 my 1   v47 my entry
- *   v48 pos    v49 probes left per lane (32; lane 0: what is left of the scan)   v50 id   v51 record offset
- *   v52-55 own 16 bytes   v56-57, v60-67 scratch   v58-59 the step's record
+ * and out).  v59 is the highest: the global-table kernel then declares 60 VGPRs -- with 64, the top four
+ * in use and eight waves on a SIMD (every VGPR of the SIMD allocated), waves read each other's values
+ * there (found the hard way: bit-exact with one wave per SIMD, wrong match lengths beside others).
+ *   v32 mlen   v33 cl   v34 cand   v35 nx   v36 entry address   v37 its dword   v38 my 1   v39 my entry
+ *   v40 pos    v41 probes left per lane (32; lane 0: what is left of the scan)   v42 id / slot   v43 record offset
+ *   v44-v47 own 16 bytes   v48-v49, v52-v59 scratch   v50-v51 the step's record
  *   s[60:61] lanes with a bucket   s[62:63] flagged   s[64:65] stops   s[66:67] special   s[68:69] taken
  *   s[70:71] candidate can match / inside a copy   s72-s79, s84-s91 scratch   s80 t   s81 lim0   s82 go
+ *   s83 the compiler's m0   s92-s93 the global table's epoch field
  * ======================================================================================== */
 #define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
 	"1:\n\t"                                                                                                           \
 	"s_bitset1_b64 s[68:69], s80\n\t"                                                                                  \
-	"v_readlane_b32 s80, v43, s80\n\t"                                                                                 \
+	"v_readlane_b32 s80, v35, s80\n\t"                                                                                 \
 	"s_nop 0\n\t"                                                                                                      \
 	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
 	"s_cbranch_scc1 1b\n\t"
@@ -614,117 +617,212 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_mad_u32_u24 " d ", " a ", " b ", " d "\n\t"    /* + the high half when the low one is all equal */              \
 	"v_lshrrev_b32_e32 " d ", 3, " d "\n\t"
 
-#define CSNAPPY_DENSE_ISA                                                                                              \
-	"v_mov_b32_e32 v49, 32\n\t"                                                                                        \
+/* the pieces that differ between the table placements: the FRONT's table access (label 12), the test for
+ * another round, the next step's loads and the commit (behind label 11) */
+#define CSNAPPY_ISA_TABLE_DENSE \
+	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
+	"v_lshlrev_b32_e32 v36, 1, v42\n\t"                /* my table entry (id 0: the dummy) */                          \
+	"ds_read_u16 v56, v36\n\t"                                                                                         \
+	"v_and_b32_e32 v37, 0xfffc, v36\n\t"               /* its dword */                                                 \
+	"v_lshlrev_b32_e32 v58, 4, v42\n\t"                /* bits 4:0 = 16 * (id & 1) */                                  \
+	"v_lshlrev_b32_e64 v38, v58, 1\n\t"                /* 1 in my half */                                              \
+	"ds_add_rtn_u32 v57, v37, v38\n\t"                 /* comes back with the lower lanes' ones in it */               \
+	"v_writelane_b32 v41, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */ \
+	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
+	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	"v_cmp_ne_u32_e64 s[60:61], 0, v42\n\t"            /* lanes with a bucket */                                       \
+	"v_lshl_or_b32 v39, v59, 15, v40\n\t"              /* my entry, if I am inserted */                                \
+	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
+	"v_xor_b32_e32 v59, v56, v39\n\t"                                                                                  \
+	"v_and_b32_e32 v34, 0x7fff, v56\n\t"                                                                               \
+	"v_cmp_lt_u32_e32 vcc, v59, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_and_b64 s[70:71], vcc, s[60:61]\n\t"            /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v59, 0, v34, s[70:71]\n\t"                                                                      \
+	"global_load_dwordx4 v[52:55], v59, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 v43, v[50:51], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_bfe_u32 v57, v57, v58, 16\n\t"                  /* my half as the add found it */                               \
+	"v_cmp_ne_u32_e32 vcc, v57, v56\n\t"               /* not the entry: a lower lane has my slot */                   \
+	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes */                                             \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */
+
+#define CSNAPPY_ISA_GO_DENSE \
+	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
+	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */
+
+#define CSNAPPY_ISA_LOADS_DENSE \
+	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"                                                                    \
+	"v_lshlrev_b32_e32 v48, 1, v49\n\t"                                                                                \
+	"global_load_ushort v42, v48, %[ids]\n\t"
+
+#define CSNAPPY_ISA_COMMIT_DENSE \
+	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
+	"ds_sub_u32 v37, v38\n\t"                          /* the adds are taken back */                                   \
+	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
+	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
+	"ds_write_b16 v36, v39\n\t"                        /* (of several with one slot the highest stays) */              \
+	"s_mov_b64 exec, -1\n\t"
+
+/* the full 2^p-byte table in global memory, an occupancy bitmap and the keyed exchange array in LDS
+ * (parse_lean<TAB_GLOBAL>): the slot is the hash; v36 = my entry's offset, v37 = my bitmap word, v38 = my bit */
+#define CSNAPPY_ISA_TABLE_GTAB \
+	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
+	"s_add_u32 s92, %[epoch], -1\n\t"                  /* this step's epoch field */                                   \
+	"s_lshl_b32 s93, s92, 22\n\t"                                                                                      \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes, and the table store of the step before */\
+	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
+	"v_lshrrev_b32_e32 v42, %[shift], v59\n\t"         /* my slot: the hash */                                         \
+	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of it */                             \
+	"v_lshl_or_b32 v39, v59, 15, v40\n\t"              /* my entry, if I am inserted */                                \
+	"v_and_b32_e32 v56, %[smask], v42\n\t"             /* key of the exchange array */                                 \
+	"v_lshl_or_b32 v57, v42, 7, %[lane]\n\t"                                                                           \
+	"v_lshl_add_u32 v56, v56, 2, %[sbase]\n\t"                                                                         \
+	"v_or_b32_e32 v57, s93, v57\n\t"                   /* tag: epoch, slot, lane */                                    \
+	"ds_wrxchg_rtn_b32 v58, v56, v57\n\t"              /* comes back with the tag the nearest lower lane with my key left */\
+	"v_lshrrev_b32_e32 v48, 3, v42\n\t"                                                                                \
+	"v_and_b32_e32 v37, 0xffc, v48\n\t"                /* my word of the occupancy bitmap */                           \
+	"ds_read_b32 v49, v37\n\t"                                                                                         \
+	"v_writelane_b32 v41, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */\
+	"v_lshlrev_b32_e32 v36, 1, v42\n\t"                /* my entry's offset in the table */                            \
+	"v_lshlrev_b32_e64 v38, v42, 1\n\t"                /* my bit of the word */                                        \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_and_b32_e32 v49, v49, v38\n\t"                                                                                  \
+	"v_cmp_ne_u32_e64 s[84:85], 0, v49\n\t"            /* written in this fragment */                                  \
+	"v_lshrrev_b32_e32 v58, 22, v58\n\t"                                                                               \
+	"v_mov_b32_e32 v57, %[zv]\n\t"                     /* (two wait states between the compare and the select) */      \
+	"v_cndmask_b32_e64 v48, 0, v36, s[84:85]\n\t"      /* (an empty slot is not read) */                               \
+	"global_load_ushort v56, v48, %[gtab]\n\t"         /* the entry */                                                 \
+	"v_cmp_eq_u32_e64 s[62:63], s92, v58\n\t"          /* flagged: a lower lane of this step has my key */             \
+	"s_waitcnt vmcnt(0)\n\t"                                                                                           \
+	"v_cndmask_b32_e64 v56, v57, v56, s[84:85]\n\t"    /* empty: position 0's entry */                                 \
+	"v_xor_b32_e32 v59, v56, v39\n\t"                                                                                  \
+	"v_and_b32_e32 v34, 0x7fff, v56\n\t"                                                                               \
+	"v_cmp_lt_u32_e32 vcc, v59, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_mov_b64 s[70:71], vcc\n\t"                      /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v59, 0, v34, s[70:71]\n\t"                                                                      \
+	"global_load_dwordx4 v[52:55], v59, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 v43, v[50:51], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */
+
+#define CSNAPPY_ISA_GO_GTAB \
+	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
+	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */                          \
+	"s_cmp_lt_u32 s92, 2\n\t"                          /* ... unless the tags' epoch field runs out: the C++ step starts the array over */\
+	"s_cselect_b32 s82, 99, s82\n\t"
+
+#define CSNAPPY_ISA_LOADS_GTAB \
+	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"
+
+#define CSNAPPY_ISA_COMMIT_GTAB \
+	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
+	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
+	"s_and_b64 s[84:85], s[62:63], s[70:71]\n\t"       /* of several with one slot only the highest may store (memory keeps no order) */\
+	"s_cmp_eq_u64 s[84:85], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 41f\n\t"                                                                                           \
+	"s_mov_b64 s[86:87], 0\n\t"                        /* one round per shared slot, highest lane first: the lower ones of its slot lose */\
+	"40:\n\t"                                                                                                          \
+	"s_flbit_i32_b64 s76, s[84:85]\n\t"                                                                                \
+	"s_xor_b32 s76, s76, 63\n\t"                                                                                       \
+	"v_readlane_b32 s77, v42, s76\n\t"                                                                                 \
+	"s_bfm_b64 s[88:89], s76, 0\n\t"                                                                                   \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_cmp_eq_u32_e32 vcc, s77, v42\n\t"                                                                               \
+	"s_and_b64 vcc, vcc, s[70:71]\n\t"                                                                                 \
+	"s_andn2_b64 s[84:85], s[84:85], vcc\n\t"                                                                          \
+	"s_and_b64 vcc, vcc, s[88:89]\n\t"                                                                                 \
+	"s_or_b64 s[86:87], s[86:87], vcc\n\t"                                                                             \
+	"s_cmp_lg_u64 s[84:85], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 40b\n\t"                                                                                           \
+	"s_andn2_b64 s[70:71], s[70:71], s[86:87]\n\t"                                                                     \
+	"41:\n\t"                                                                                                          \
+	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
+	"global_store_short v36, v39, %[gtab]\n\t"         /* table[slot] = my entry */                                    \
+	"ds_or_b32 v37, v38\n\t"                           /* ... and the slot is occupied */                              \
+	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	"s_mov_b32 %[epoch], s92\n\t"                      /* one epoch per step */
+
+#define CSNAPPY_ISA_LOOP(ENTRY, TABLE, GO, LOADS, COMMIT)                                                           \
+	"v_mov_b32_e32 v41, 32\n\t"                                                                                        \
 	"s_mov_b32 s83, m0\n\t"                            /* (m0 is the compiler's: given back at 19) */                  \
+	ENTRY                                                                                                              \
 	"s_branch 12f\n\t"                                                                                                 \
 	/* ================= BACK: the walk has left the step and took at least one copy ================= */            \
 	"10:\n\t"                                                                                                          \
 	"s_flbit_i32_b64 s72, s[68:69]\n\t"                                                                                \
 	"s_xor_b32 s72, s72, 63\n\t"                       /* the last copy's lane */                                      \
-	"v_mov_b32_e32 v66, %[nemit]\n\t"                  /* where the pending literal starts */                          \
-	"v_readlane_b32 s73, v41, s72\n\t"                 /* c: the lane behind the last copy */                          \
-	"v_add_u32_e32 v67, %[p0], v41\n\t"                /* where my copy ends */                                        \
+	"v_mov_b32_e32 v58, %[nemit]\n\t"                  /* where the pending literal starts */                          \
+	"v_readlane_b32 s73, v33, s72\n\t"                 /* c: the lane behind the last copy */                          \
+	"v_add_u32_e32 v59, %[p0], v33\n\t"                /* where my copy ends */                                        \
 	"s_bcnt1_i32_b64 s78, s[68:69]\n\t"                                                                                \
-	"v_cndmask_b32_e64 v67, v66, v67, s[68:69]\n\t"                                                                    \
+	"v_cndmask_b32_e64 v59, v58, v59, s[68:69]\n\t"                                                                    \
 	"s_add_u32 %[nemit], %[p0], s73\n\t"               /* next_emit: behind the last copy */                           \
 	"s_add_u32 s74, s73, 32\n\t"                                                                                       \
-	"v_max_u32_dpp v67, v67, v67 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v59, v59, v59 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_min_u32 s74, s74, 63\n\t"                       /* e: the last lane the step probes */                          \
 	"s_add_u32 s75, s73, -1\n\t"                       /* c - 1 */                                                     \
-	"v_max_u32_dpp v67, v67, v67 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v59, v59, v59 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_sub_u32 s76, s74, s75\n\t"                      /* probes of the scan behind the copy: e - c + 1 */             \
 	"s_cmp_ge_u32 s73, 64\n\t"                         /* the copy leaves the step: re-match probe next */             \
-	"v_max_u32_dpp v67, v67, v67 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v59, v59, v59 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_cselect_b32 s75, s75, s74\n\t"                  /* lane 0 of the next step */                                   \
 	"s_cselect_b32 %[q1], 0, s76\n\t"                                                                                  \
-	"v_max_u32_dpp v67, v67, v67 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v59, v59, v59 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_cselect_b32 s72, s72, s74\n\t"                  /* e_final: the last lane that is inserted */                   \
 	"s_mov_b64 vcc, s[68:69]\n\t"                                                                                      \
-	"v_max_u32_dpp v67, v67, v67 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
-	"v_mbcnt_lo_u32_b32 v56, vcc_lo, 0\n\t"                                                                            \
-	"v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t"          /* taken lanes below me */                                      \
-	"v_max_u32_dpp v67, v67, v67 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
-	"v_lshl_or_b32 v58, v42, 16, v48\n\t"              /* record: base | cand << 16 */                                 \
-	"v_add_u32_e32 v57, 1, v48\n\t"                                                                                    \
-	"v_mov_b32_dpp v66, v67 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */ \
+	"v_max_u32_dpp v59, v59, v59 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
+	"v_mbcnt_lo_u32_b32 v48, vcc_lo, 0\n\t"                                                                            \
+	"v_mbcnt_hi_u32_b32 v48, vcc_hi, v48\n\t"          /* taken lanes below me */                                      \
+	"v_max_u32_dpp v59, v59, v59 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
+	"v_lshl_or_b32 v50, v34, 16, v40\n\t"              /* record: base | cand << 16 */                                 \
+	"v_add_u32_e32 v49, 1, v40\n\t"                                                                                    \
+	"v_mov_b32_dpp v58, v59 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */ \
 	"s_add_u32 %[p0], %[p0], s75\n\t"                  /* pz */                                                        \
-	"v_add_lshl_u32 v56, v56, %[nev], 3\n\t"           /* my record's byte offset */                                   \
+	"v_add_lshl_u32 v48, v48, %[nev], 3\n\t"           /* my record's byte offset */                                   \
 	"s_add_u32 %[nev], %[nev], s78\n\t"                                                                                \
-	"v_lshl_or_b32 v59, v66, 16, v40\n\t"              /* record: copy_len | lit_start << 16 */                        \
-	"v_cmp_lt_u32_e64 s[70:71], v57, v66\n\t"          /* strictly inside a copy: never inserted */                    \
-	"v_cndmask_b32_e64 v51, %[norec], v56, s[68:69]\n\t"                                                               \
+	"v_lshl_or_b32 v51, v58, 16, v32\n\t"              /* record: copy_len | lit_start << 16 */                        \
+	"v_cmp_lt_u32_e64 s[70:71], v49, v58\n\t"          /* strictly inside a copy: never inserted */                    \
+	"v_cndmask_b32_e64 v43, %[norec], v48, s[68:69]\n\t"                                                               \
 	/* ---- 11: the cursor is known: the next step's loads, then this step's commit ---- */                         \
 	"11:\n\t"                                                                                                          \
-	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
-	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */                          \
-	"v_add_u32_e32 v48, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
-	"v_min_u32_e32 v57, %[safemax], v48\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
-	"global_load_dwordx4 v[52:55], v57, %[src]\n\t"                                                                    \
-	"v_lshlrev_b32_e32 v56, 1, v57\n\t"                                                                                \
-	"global_load_ushort v50, v56, %[ids]\n\t"                                                                          \
-	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
-	"ds_sub_u32 v45, v46\n\t"                          /* the adds are taken back */                                   \
-	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
-	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
-	"ds_write_b16 v44, v47\n\t"                        /* (of several with one slot the highest stays) */              \
-	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	GO                                                                                                                 \
+	LOADS                                                                                                              \
+	COMMIT                                                                                                             \
 	"s_cmp_lt_u32 s82, 33\n\t"                                                                                         \
 	"s_cbranch_scc0 19f\n\t"                                                                                           \
 	/* ================= FRONT ================= */                                                                  \
 	"12:\n\t"                                                                                                          \
-	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
-	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
-	"v_lshlrev_b32_e32 v44, 1, v50\n\t"                /* my table entry (id 0: the dummy) */                          \
-	"ds_read_u16 v64, v44\n\t"                                                                                         \
-	"v_and_b32_e32 v45, 0xfffc, v44\n\t"               /* its dword */                                                 \
-	"v_lshlrev_b32_e32 v66, 4, v50\n\t"                /* bits 4:0 = 16 * (id & 1) */                                  \
-	"v_lshlrev_b32_e64 v46, v66, 1\n\t"                /* 1 in my half */                                              \
-	"ds_add_rtn_u32 v65, v45, v46\n\t"                 /* comes back with the lower lanes' ones in it */               \
-	"v_writelane_b32 v49, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */ \
-	"v_mul_lo_u32 v67, v52, %[mul]\n\t"                                                                                \
-	"v_bfe_u32 v67, v67, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
-	"v_cmp_ne_u32_e64 s[60:61], 0, v50\n\t"            /* lanes with a bucket */                                       \
-	"v_lshl_or_b32 v47, v67, 15, v48\n\t"              /* my entry, if I am inserted */                                \
-	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
-	"v_xor_b32_e32 v67, v64, v47\n\t"                                                                                  \
-	"v_and_b32_e32 v42, 0x7fff, v64\n\t"                                                                               \
-	"v_cmp_lt_u32_e32 vcc, v67, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
-	"s_and_b64 s[70:71], vcc, s[60:61]\n\t"            /* the candidate can match at all */                            \
-	"v_cndmask_b32_e64 v67, 0, v42, s[70:71]\n\t"                                                                      \
-	"global_load_dwordx4 v[60:63], v67, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
-	"global_store_dwordx2 v51, v[58:59], %[R]\n\t"     /* the previous step's records, behind the gather */            \
-	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
-	"v_bfe_u32 v65, v65, v66, 16\n\t"                  /* my half as the add found it */                               \
-	"v_cmp_ne_u32_e32 vcc, v65, v64\n\t"               /* not the entry: a lower lane has my slot */                   \
-	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes */                                             \
-	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */                  \
-	"v_xor_b32_e32 v60, v60, v52\n\t"                                                                                  \
-	"v_xor_b32_e32 v61, v61, v53\n\t"                                                                                  \
-	"v_xor_b32_e32 v62, v62, v54\n\t"                                                                                  \
-	"v_xor_b32_e32 v63, v63, v55\n\t"                                                                                  \
-	CSNAPPY_ISA_PREFIX16("v60", "v61", "v62", "v63")                                                                   \
-	"v_cndmask_b32_e64 v40, 0, v60, s[70:71]\n\t"      /* lane-local match length, 0..16 */                            \
-	"v_cmp_lt_u32_e64 s[64:65], 3, v40\n\t"            /* matches */                                                   \
-	"v_cmp_eq_u32_e32 vcc, 16, v40\n\t"                /* may be longer */                                             \
-	"v_add_u32_e32 v41, %[lane], v40\n\t"              /* lane of the re-match probe behind my match */                \
+	TABLE                                                                                                              \
+	"v_xor_b32_e32 v52, v52, v44\n\t"                                                                                  \
+	"v_xor_b32_e32 v53, v53, v45\n\t"                                                                                  \
+	"v_xor_b32_e32 v54, v54, v46\n\t"                                                                                  \
+	"v_xor_b32_e32 v55, v55, v47\n\t"                                                                                  \
+	CSNAPPY_ISA_PREFIX16("v52", "v53", "v54", "v55")                                                                   \
+	"v_cndmask_b32_e64 v32, 0, v52, s[70:71]\n\t"      /* lane-local match length, 0..16 */                            \
+	"v_cmp_lt_u32_e64 s[64:65], 3, v32\n\t"            /* matches */                                                   \
+	"v_cmp_eq_u32_e32 vcc, 16, v32\n\t"                /* may be longer */                                             \
+	"v_add_u32_e32 v33, %[lane], v32\n\t"              /* lane of the re-match probe behind my match */                \
 	"s_or_b64 s[64:65], s[64:65], s[62:63]\n\t"        /* stops of the chain: matches and flagged lanes */             \
 	"s_or_b64 s[66:67], vcc, s[62:63]\n\t"             /* ... that need a visit */                                     \
-	"v_lshrrev_b64 v[56:57], v41, s[64:65]\n\t"                                                                        \
-	"v_sub_u32_e32 v62, 63, v41\n\t"                   /* lanes left behind my match (negative: none) */               \
-	"v_ffbl_b32_e32 v57, v57\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v56, v56\n\t"                                                                                      \
-	"v_add_u32_e64 v57, v57, 32 clamp\n\t"                                                                             \
-	"v_min_i32_e32 v62, v62, v49\n\t"                  /* ... and probes */                                            \
-	"v_min3_u32 v56, v56, v57, 64\n\t"                 /* distance to the next stop */                                 \
-	"v_add_u32_e32 v63, v41, v56\n\t"                  /* its lane */                                                  \
-	"v_cmp_le_i32_e32 vcc, v56, v62\n\t"                                                                               \
-	"v_lshrrev_b64 v[60:61], v63, s[66:67]\n\t"                                                                        \
-	"v_and_b32_e32 v60, 1, v60\n\t"                                                                                    \
-	"v_lshl_or_b32 v64, v60, 7, v63\n\t"               /* lane | 128: a special one */                                 \
-	"v_cndmask_b32_e32 v43, 64, v64, vcc\n\t"          /* next stop of the chain if my match is taken (64: none here) */ \
+	"v_lshrrev_b64 v[48:49], v33, s[64:65]\n\t"                                                                        \
+	"v_sub_u32_e32 v54, 63, v33\n\t"                   /* lanes left behind my match (negative: none) */               \
+	"v_ffbl_b32_e32 v49, v49\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v48, v48\n\t"                                                                                      \
+	"v_add_u32_e64 v49, v49, 32 clamp\n\t"                                                                             \
+	"v_min_i32_e32 v54, v54, v41\n\t"                  /* ... and probes */                                            \
+	"v_min3_u32 v48, v48, v49, 64\n\t"                 /* distance to the next stop */                                 \
+	"v_add_u32_e32 v55, v33, v48\n\t"                  /* its lane */                                                  \
+	"v_cmp_le_i32_e32 vcc, v48, v54\n\t"                                                                               \
+	"v_lshrrev_b64 v[52:53], v55, s[66:67]\n\t"                                                                        \
+	"v_and_b32_e32 v52, 1, v52\n\t"                                                                                    \
+	"v_lshl_or_b32 v56, v52, 7, v55\n\t"               /* lane | 128: a special one */                                 \
+	"v_cndmask_b32_e32 v35, 64, v56, vcc\n\t"          /* next stop of the chain if my match is taken (64: none here) */ \
 	"s_mov_b64 s[68:69], 0\n\t"                                                                                        \
-	"v_readlane_b32 s80, v43, 0\n\t"                   /* the walk: lane 0 holds the first stop */                     \
+	"v_readlane_b32 s80, v35, 0\n\t"                   /* the walk: lane 0 holds the first stop */                     \
 	"s_nop 0\n\t"                                                                                                      \
 	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
 	"s_cbranch_scc0 13f\n\t"                           /* none, or a special lane */                                   \
@@ -737,16 +835,16 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_cbranch_scc1 14f\n\t"                           /* 64 / 65: the walk left the step */                           \
 	"s_and_b32 s73, s80, 63\n\t"                       /* i */                                                         \
 	"s_mov_b32 m0, s73\n\t"                            /* (v_writelane takes one SGPR: its lane select goes through m0) */ \
-	"v_readlane_b32 s74, v40, s73\n\t"                 /* L: its lane-local match length */                            \
+	"v_readlane_b32 s74, v32, s73\n\t"                 /* L: its lane-local match length */                            \
 	"s_bitcmp1_b64 s[62:63], s73\n\t"                                                                                  \
 	"s_cbranch_scc0 30f\n\t"                           /* not flagged: a match of 16 bytes that may be longer */       \
 	/* ---- a flagged lane: its candidate is the latest position inserted for its slot -- the highest lane    \
 	 * below it with the same slot that this step inserts (not strictly inside a copy of the chain), whose   \
 	 * bytes are that lane's own 16 bytes -- else the table entry it compared with ---- */                          \
-	"v_readlane_b32 s75, v50, s73\n\t"                 /* its slot */                                                  \
+	"v_readlane_b32 s75, v42, s73\n\t"                 /* its slot */                                                  \
 	"s_bfm_b64 s[84:85], s73, 0\n\t"                   /* lanes below i */                                             \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_cmp_eq_u32_e32 vcc, s75, v50\n\t"                                                                               \
+	"v_cmp_eq_u32_e32 vcc, s75, v42\n\t"                                                                               \
 	"s_and_b64 s[86:87], vcc, s[60:61]\n\t"                                                                            \
 	"s_and_b64 s[86:87], s[86:87], s[84:85]\n\t"       /* same: lanes below i with its slot */                         \
 	"s_cmp_eq_u64 s[86:87], 0\n\t"                                                                                     \
@@ -762,51 +860,51 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_cbranch_scc1 23f\n\t"                                                                                           \
 	"s_flbit_i32_b64 s77, s[88:89]\n\t"                                                                                \
 	"s_xor_b32 s77, s77, 63\n\t"                                                                                       \
-	"v_readlane_b32 s77, v41, s77\n\t"                 /* where the nearest of them ends */                            \
+	"v_readlane_b32 s77, v33, s77\n\t"                 /* where the nearest of them ends */                            \
 	"s_add_u32 s78, s76, 1\n\t"                                                                                        \
 	"s_cmp_lt_u32 s78, s77\n\t"                                                                                        \
 	"s_cbranch_scc0 23f\n\t"                           /* jh was inserted */                                           \
 	/* it was not: settle all of `same` at once -- the end of the nearest taken copy below every lane is the  \
 	 * running maximum of the taken lanes' ends (they grow along the chain) */                                      \
-	"v_cndmask_b32_e64 v64, 0, v41, s[68:69]\n\t"                                                                      \
-	"v_add_u32_e32 v66, 1, %[lane]\n\t"                                                                                \
+	"v_cndmask_b32_e64 v56, 0, v33, s[68:69]\n\t"                                                                      \
+	"v_add_u32_e32 v58, 1, %[lane]\n\t"                                                                                \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v56, v56, v56 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_nop 1\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v56, v56, v56 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_nop 1\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v56, v56, v56 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_nop 1\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_max_u32_dpp v56, v56, v56 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_nop 1\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
+	"v_max_u32_dpp v56, v56, v56 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
 	"s_nop 1\n\t"                                                                                                      \
-	"v_max_u32_dpp v64, v64, v64 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
-	"v_mov_b32_e32 v65, 0\n\t"                                                                                         \
+	"v_max_u32_dpp v56, v56, v56 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
+	"v_mov_b32_e32 v57, 0\n\t"                                                                                         \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_mov_b32_dpp v65, v64 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                                 \
+	"v_mov_b32_dpp v57, v56 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                                 \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_cmp_lt_u32_e32 vcc, v66, v65\n\t"               /* lane + 1 < that end: never inserted */                       \
+	"v_cmp_lt_u32_e32 vcc, v58, v57\n\t"               /* lane + 1 < that end: never inserted */                       \
 	"s_andn2_b64 s[86:87], s[86:87], vcc\n\t"                                                                          \
 	"s_cmp_eq_u64 s[86:87], 0\n\t"                                                                                     \
 	"s_cbranch_scc1 24f\n\t"                                                                                           \
 	"23:\n\t"                                          /* j: the highest lane of `same`; its bytes against everyone's */ \
 	"s_flbit_i32_b64 s76, s[86:87]\n\t"                                                                                \
 	"s_xor_b32 s76, s76, 63\n\t"                                                                                       \
-	"v_readlane_b32 s88, v52, s76\n\t"                                                                                 \
-	"v_readlane_b32 s89, v53, s76\n\t"                                                                                 \
-	"v_readlane_b32 s90, v54, s76\n\t"                                                                                 \
-	"v_readlane_b32 s91, v55, s76\n\t"                                                                                 \
+	"v_readlane_b32 s88, v44, s76\n\t"                                                                                 \
+	"v_readlane_b32 s89, v45, s76\n\t"                                                                                 \
+	"v_readlane_b32 s90, v46, s76\n\t"                                                                                 \
+	"v_readlane_b32 s91, v47, s76\n\t"                                                                                 \
 	"s_add_u32 s77, %[p0], s76\n\t"                    /* its position */                                              \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_xor_b32_e32 v60, s88, v52\n\t"                                                                                  \
-	"v_xor_b32_e32 v61, s89, v53\n\t"                                                                                  \
-	"v_xor_b32_e32 v62, s90, v54\n\t"                                                                                  \
-	"v_xor_b32_e32 v63, s91, v55\n\t"                                                                                  \
-	CSNAPPY_ISA_PREFIX16("v60", "v61", "v62", "v63")                                                                   \
+	"v_xor_b32_e32 v52, s88, v44\n\t"                                                                                  \
+	"v_xor_b32_e32 v53, s89, v45\n\t"                                                                                  \
+	"v_xor_b32_e32 v54, s90, v46\n\t"                                                                                  \
+	"v_xor_b32_e32 v55, s91, v47\n\t"                                                                                  \
+	CSNAPPY_ISA_PREFIX16("v52", "v53", "v54", "v55")                                                                   \
 	"s_nop 0\n\t"                                                                                                      \
-	"v_readlane_b32 s74, v60, s73\n\t"                 /* L: lane i's match length against it */                       \
-	"v_writelane_b32 v42, s77, m0\n\t"                 /* and its candidate */                                         \
+	"v_readlane_b32 s74, v52, s73\n\t"                 /* L: lane i's match length against it */                       \
+	"v_writelane_b32 v34, s77, m0\n\t"                 /* and its candidate */                                         \
 	"24:\n\t"                                                                                                          \
 	"s_cmp_lt_u32 s74, 4\n\t"                                                                                          \
 	"s_cbranch_scc0 30f\n\t"                                                                                           \
@@ -816,7 +914,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_cbranch_scc1 25f\n\t"                                                                                           \
 	"s_flbit_i32_b64 s77, s[68:69]\n\t"                                                                                \
 	"s_xor_b32 s77, s77, 63\n\t"                                                                                       \
-	"v_readlane_b32 s77, v41, s77\n\t"                                                                                 \
+	"v_readlane_b32 s77, v33, s77\n\t"                                                                                 \
 	"s_add_u32 s77, s77, 32\n\t"                       /* ... or the 33 behind the last copy */                        \
 	"25:\n\t"                                                                                                          \
 	"s_bitset1_b64 s[84:85], s73\n\t"                  /* lanes up to i */                                             \
@@ -843,38 +941,38 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_add_u32 s76, s76, 16\n\t"                       /* mb = base + 16 */                                            \
 	"s_cmp_lt_u32 s76, %[n]\n\t"                                                                                       \
 	"s_cbranch_scc0 35f\n\t"                                                                                           \
-	"v_readlane_b32 s77, v42, s73\n\t"                                                                                 \
+	"v_readlane_b32 s77, v34, s73\n\t"                                                                                 \
 	"s_sub_u32 s78, %[n], s76\n\t"                     /* lim: bytes left behind mb */                                 \
 	"s_mov_b32 s79, 0\n\t"                             /* done */                                                      \
-	"v_lshlrev_b32_e32 v64, 3, %[lane]\n\t"                                                                            \
+	"v_lshlrev_b32_e32 v56, 3, %[lane]\n\t"                                                                            \
 	"s_add_u32 s77, s77, 16\n\t"                       /* ma = cand + 16 */                                            \
 	"31:\n\t"                                                                                                          \
-	"v_add_u32_e32 v65, s79, v64\n\t"                  /* o = done + 8 * lane */                                       \
-	"v_sub_u32_e32 v66, s78, v65\n\t"                                                                                  \
-	"v_cmp_gt_u32_e64 s[84:85], s78, v65\n\t"          /* o < lim: my eight bytes begin inside the fragment */         \
-	"v_min_u32_e32 v66, 8, v66\n\t"                    /* r: how many of them are inside */                            \
-	"v_sub_u32_e32 v67, 8, v66\n\t"                    /* back: read the eight bytes that END at the fragment's end */ \
-	"v_sub_u32_e32 v60, v65, v67\n\t"                                                                                  \
-	"v_cndmask_b32_e64 v60, 0, v60, s[84:85]\n\t"                                                                      \
-	"v_add_u32_e32 v61, s77, v60\n\t"                                                                                  \
-	"v_add_u32_e32 v60, s76, v60\n\t"                                                                                  \
-	"global_load_dwordx2 v[56:57], v61, %[src]\n\t"                                                                    \
-	"global_load_dwordx2 v[62:63], v60, %[src]\n\t"                                                                    \
-	"v_lshlrev_b32_e32 v67, 3, v67\n\t"                                                                                \
-	"v_add_u32_e32 v61, 8, v65\n\t"                                                                                    \
+	"v_add_u32_e32 v57, s79, v56\n\t"                  /* o = done + 8 * lane */                                       \
+	"v_sub_u32_e32 v58, s78, v57\n\t"                                                                                  \
+	"v_cmp_gt_u32_e64 s[84:85], s78, v57\n\t"          /* o < lim: my eight bytes begin inside the fragment */         \
+	"v_min_u32_e32 v58, 8, v58\n\t"                    /* r: how many of them are inside */                            \
+	"v_sub_u32_e32 v59, 8, v58\n\t"                    /* back: read the eight bytes that END at the fragment's end */ \
+	"v_sub_u32_e32 v52, v57, v59\n\t"                                                                                  \
+	"v_cndmask_b32_e64 v52, 0, v52, s[84:85]\n\t"                                                                      \
+	"v_add_u32_e32 v53, s77, v52\n\t"                                                                                  \
+	"v_add_u32_e32 v52, s76, v52\n\t"                                                                                  \
+	"global_load_dwordx2 v[48:49], v53, %[src]\n\t"                                                                    \
+	"global_load_dwordx2 v[54:55], v52, %[src]\n\t"                                                                    \
+	"v_lshlrev_b32_e32 v59, 3, v59\n\t"                                                                                \
+	"v_add_u32_e32 v53, 8, v57\n\t"                                                                                    \
 	"s_waitcnt vmcnt(0)\n\t"                                                                                           \
-	"v_xor_b32_e32 v56, v56, v62\n\t"                                                                                  \
-	"v_xor_b32_e32 v57, v57, v63\n\t"                                                                                  \
-	"v_lshrrev_b64 v[56:57], v67, v[56:57]\n\t"        /* drop the bytes in front of o */                              \
-	"v_cmp_le_u32_e32 vcc, s78, v61\n\t"               /* o + 8 >= lim: the fragment ends in my bytes */               \
-	"v_ffbl_b32_e32 v60, v56\n\t"                                                                                      \
-	"v_ffbl_b32_e32 v62, v57\n\t"                                                                                      \
-	"v_add_u32_e64 v62, v62, 32 clamp\n\t"                                                                             \
-	"v_min3_u32 v60, v60, v62, 64\n\t"                                                                                 \
-	"v_lshrrev_b32_e32 v60, 3, v60\n\t"                /* equal bytes (8: all) */                                      \
-	"v_min_u32_e32 v60, v60, v66\n\t"                                                                                  \
-	"v_cndmask_b32_e64 v60, 0, v60, s[84:85]\n\t"      /* m8 (lanes beyond the fragment: 0) */                         \
-	"v_cmp_gt_u32_e64 s[86:87], 8, v60\n\t"            /* the match ends in my bytes */                                \
+	"v_xor_b32_e32 v48, v48, v54\n\t"                                                                                  \
+	"v_xor_b32_e32 v49, v49, v55\n\t"                                                                                  \
+	"v_lshrrev_b64 v[48:49], v59, v[48:49]\n\t"        /* drop the bytes in front of o */                              \
+	"v_cmp_le_u32_e32 vcc, s78, v53\n\t"               /* o + 8 >= lim: the fragment ends in my bytes */               \
+	"v_ffbl_b32_e32 v52, v48\n\t"                                                                                      \
+	"v_ffbl_b32_e32 v54, v49\n\t"                                                                                      \
+	"v_add_u32_e64 v54, v54, 32 clamp\n\t"                                                                             \
+	"v_min3_u32 v52, v52, v54, 64\n\t"                                                                                 \
+	"v_lshrrev_b32_e32 v52, 3, v52\n\t"                /* equal bytes (8: all) */                                      \
+	"v_min_u32_e32 v52, v52, v58\n\t"                                                                                  \
+	"v_cndmask_b32_e64 v52, 0, v52, s[84:85]\n\t"      /* m8 (lanes beyond the fragment: 0) */                         \
+	"v_cmp_gt_u32_e64 s[86:87], 8, v52\n\t"            /* the match ends in my bytes */                                \
 	"s_or_b64 s[86:87], s[86:87], vcc\n\t"                                                                             \
 	"s_cmp_lg_u64 s[86:87], 0\n\t"                                                                                     \
 	"s_cbranch_scc1 32f\n\t"                                                                                           \
@@ -882,15 +980,15 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_branch 31b\n\t"                                                                                                 \
 	"32:\n\t"                                                                                                          \
 	"s_ff1_i32_b64 s88, s[86:87]\n\t"                  /* the first lane it ends in */                                 \
-	"v_readlane_b32 s89, v60, s88\n\t"                                                                                 \
+	"v_readlane_b32 s89, v52, s88\n\t"                                                                                 \
 	"s_lshl_b32 s88, s88, 3\n\t"                                                                                       \
 	"s_add_u32 s79, s79, s88\n\t"                                                                                      \
 	"s_add_u32 s79, s79, s89\n\t"                                                                                      \
 	"s_add_u32 s74, s79, 16\n\t"                       /* L */                                                         \
 	"35:\n\t"                                          /* the copy is taken */                                         \
 	"s_add_u32 s75, s73, s74\n\t"                      /* the lane behind it */                                        \
-	"v_writelane_b32 v40, s74, m0\n\t"                                                                                 \
-	"v_writelane_b32 v41, s75, m0\n\t"                                                                                 \
+	"v_writelane_b32 v32, s74, m0\n\t"                                                                                 \
+	"v_writelane_b32 v33, s75, m0\n\t"                                                                                 \
 	"s_bitset1_b64 s[68:69], s73\n\t"                                                                                  \
 	/* the next stop behind it, on the scalar unit (64: the re-match probe falls outside the step; 65: none  \
 	 * of the 33 probes behind the copy is a stop) */                                                               \
@@ -919,9 +1017,9 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	/* no copy in the whole step: the scan goes on behind its last probe (csnappy_compress.c:535-552);       \
 	 * nothing to record; every lane up to that probe is inserted */                                                \
 	"s_min_u32 s72, s81, 63\n\t"                       /* e_final */                                                   \
-	"v_mov_b32_e32 v58, 0\n\t"                                                                                         \
-	"v_mov_b32_e32 v59, 0\n\t"                                                                                         \
-	"v_mov_b32_e32 v51, %[norec]\n\t"                                                                                  \
+	"v_mov_b32_e32 v50, 0\n\t"                                                                                         \
+	"v_mov_b32_e32 v51, 0\n\t"                                                                                         \
+	"v_mov_b32_e32 v43, %[norec]\n\t"                                                                                  \
 	"s_add_u32 %[q1], %[q1], s72\n\t"                                                                                  \
 	"s_add_u32 %[p0], %[p0], s72\n\t"                                                                                  \
 	"s_mov_b64 s[70:71], 0\n\t"                                                                                        \
@@ -1211,8 +1309,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			}
 		};
 
-		/* the step loop in ISA for the common case (CSNAPPY_DENSE_ISA above) */
+		/* the step loop in ISA for the common case (CSNAPPY_ISA_LOOP above) */
 		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
+		constexpr bool FAST_G = CSNAPPY_FAST && GTAB && ORD && !PROF; /* the same loop around the global table */
 		/* a step is fast-eligible when it is dense (q1 <= 32) and pz + 64 < ip_limit: every lane is valid,
 		 * and so is every lane's p0 + lane + 16 < n */
 		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
@@ -1222,25 +1321,53 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 			if constexpr (FAST) if (q1 <= 32 && pz < limit64) {
 				/* the values C++ hands over, in the registers the block keeps them in: the step's own
 				 * bytes, id and position (place() requested them), the pending record */
-				register uint32_t x0 asm("v52") = raw0, x1 asm("v53") = raw1, x2 asm("v54") = raw2, x3 asm("v55") = raw3;
-				register uint32_t vsid asm("v50") = sid, vpos asm("v48") = pos;
-				register uint32_t px asm("v58") = prec.x, py asm("v59") = prec.y, poff asm("v51") = prec_off;
+				register uint32_t x0 asm("v44") = raw0, x1 asm("v45") = raw1, x2 asm("v46") = raw2, x3 asm("v47") = raw3;
+				register uint32_t vsid asm("v42") = sid, vpos asm("v40") = pos;
+				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
 				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
 				uint32_t nemit = next_emit;
-				asm volatile(CSNAPPY_DENSE_ISA
+				asm volatile(CSNAPPY_ISA_LOOP("", CSNAPPY_ISA_TABLE_DENSE, CSNAPPY_ISA_GO_DENSE, CSNAPPY_ISA_LOADS_DENSE,
+							      CSNAPPY_ISA_COMMIT_DENSE)
 					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0), "+v"(x1),
 					       "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
 					     : [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shift - 1), [mul] "s"(kHashMul),
 					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n), [lane] "v"(lane), [thr] "v"(thr),
 					       [norec] "v"(no_rec_off)
-					     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v49", "v56", "v57", "v60", "v61",
-					       "v62", "v63", "v64", "v65", "v66", "v67", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v48", "v49", "v52", "v53",
+					       "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
 					       "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
 					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc",
 					       "scc", "memory");
 				/* (the loads its last step requested are still on their way: clamped addresses, nobody
 				 * wants them) */
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
+				next_emit = nemit;
+				prec = make_uint2(px, py);
+				prec_off = poff;
+				fin = pz + 1 >= ip_limit;
+				place();
+				continue;
+			}
+			if constexpr (FAST_G) if (q1 <= 32 && pz < limit64 && epoch >= 2) {
+				register uint32_t x0 asm("v44") = raw0, x1 asm("v45") = raw1, x2 asm("v46") = raw2, x3 asm("v47") = raw3;
+				register uint32_t vpos asm("v40") = pos;
+				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
+				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
+				uint32_t nemit = next_emit;
+				asm volatile(CSNAPPY_ISA_LOOP("s_mov_b64 s[60:61], -1\n\t", CSNAPPY_ISA_TABLE_GTAB, CSNAPPY_ISA_GO_GTAB,
+							      CSNAPPY_ISA_LOADS_GTAB, CSNAPPY_ISA_COMMIT_GTAB)
+					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), [epoch] "+s"(epoch),
+					       "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					     : [src] "s"(src), [R] "s"(R), [gtab] "s"(gtab), [shm1] "s"(shift - 1), [shift] "s"(shift),
+					       [mul] "s"(kHashMul), [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n),
+					       [smask] "s"(smask), [sbase] "s"(A.lds0), [zv] "s"(chk0 << 15), [lane] "v"(lane), [thr] "v"(thr),
+					       [norec] "v"(no_rec_off)
+					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v42", "v48", "v49", "v52",
+					       "v53", "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65",
+					       "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",
+					       "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+					       "s92", "s93", "vcc", "scc", "memory");
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 				next_emit = nemit;
 				prec = make_uint2(px, py);
 				prec_off = poff;
