@@ -60,6 +60,9 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu; /* csnappy_compress.c:230 */
 #ifndef CSNAPPY_PARSE_NOSPILLSTORE
 #define CSNAPPY_PARSE_NOSPILLSTORE 0
 #endif
+#ifndef CSNAPPY_TIMING_TA
+#define CSNAPPY_TIMING_TA 0
+#endif
 #ifndef CSNAPPY_FAST
 #define CSNAPPY_FAST 1 /* 0: no hand-written fast path in the dense parser (A/B, and the reference for its logic) */
 #endif
@@ -571,8 +574,8 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  *   13: VISIT   the walk stands at a special lane (a flagged one, or a match of all 16 bytes that
  *               may be longer): settled as parse_lean's visits() does, the walk goes on
  *   14:         no copy in the whole step: the scan goes on behind its last probe
- *   10: BACK    cursor, records (running maximum of the copies' ends by DPP), 11: the next step's
- *               loads, commit; leaves at 19 when the next step is not one for this loop
+ *   10: BACK    cursor, the next step's loads, records (running maximum of the copies' ends by DPP),
+ *               15: commit; leaves at 19 when the next step is not one for this loop
  *
  * 239 instructions on the common path of round 5's compiled step, ~145 here.  The compiler's version
  * spends the difference on boolean round trips (v_cndmask 0/1 + v_cmp for every ballot of a combined
@@ -596,6 +599,37 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  *   s[70:71] candidate can match / inside a copy   s72-s79, s84-s91 scratch   s80 t   s81 lim0   s82 go
  *   s83 the compiler's m0   s92-s93 the global table's epoch field
  * ======================================================================================== */
+#if CSNAPPY_TIMING_TA == 1 /* timing experiment: one more 16-byte-per-lane load per step (is the texture addresser the bound?) */
+#define CSNAPPY_TIMING_EXTRA_LOAD "global_load_dwordx4 v[44:47], v49, %[src]\n\t"
+#elif CSNAPPY_TIMING_TA == 2 /* ... or eight more vector instructions */
+#define CSNAPPY_TIMING_EXTRA_LOAD "v_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\tv_add_u32_e32 v56, 1, v56\n\t"
+#else
+#define CSNAPPY_TIMING_EXTRA_LOAD ""
+#endif
+/* The step's own bytes.  Sixteen bytes per lane at byte stride 1 are 1 KiB of requests for 79 bytes, and
+ * the texture addresser is what this kernel saturates (one more such load per step: +13 % time; eight more
+ * vector instructions: +0.7 %): the window is loaded ONCE as aligned dwords, lane l dword l, one coalesced
+ * request, and every lane picks its five dwords out of the others' registers (ds_bpermute: the LDS crossbar,
+ * no memory) and shifts its 16 bytes into place.
+ * Measured: it pays around the global table (G_low 4.10 -> 3.99 ms per GiB of compress), and costs the dense
+ * table 2 % (text 8.12 -> 8.28, pages 6.16 -> 6.29): there the step's latency counts for more than the
+ * addresser's time, and the five permutes sit in front of everything the step does.  So the dense loop keeps
+ * its 16 bytes per lane, the global-table loop takes the window. */
+#define CSNAPPY_ISA_OWN_BYTES \
+	"s_and_b32 s79, %[p0], 3\n\t"                                                                                      \
+	"v_add_u32_e32 v59, s79, %[lane]\n\t"              /* where my 16 bytes begin in the window of dwords lane l holds dword l of */\
+	"v_and_b32_e32 v48, -4, v59\n\t"                                                                                   \
+	"ds_bpermute_b32 v52, v48, v44\n\t"                                                                                \
+	"ds_bpermute_b32 v53, v48, v44 offset:4\n\t"                                                                       \
+	"ds_bpermute_b32 v56, v48, v44 offset:8\n\t"                                                                       \
+	"ds_bpermute_b32 v57, v48, v44 offset:12\n\t"                                                                      \
+	"ds_bpermute_b32 v58, v48, v44 offset:16\n\t"                                                                      \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_alignbyte_b32 v44, v53, v52, v59\n\t"           /* my own 16 bytes */                                           \
+	"v_alignbyte_b32 v45, v56, v53, v59\n\t"                                                                           \
+	"v_alignbyte_b32 v46, v57, v56, v59\n\t"                                                                           \
+	"v_alignbyte_b32 v47, v58, v57, v59\n\t"
+
 #define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
 	"1:\n\t"                                                                                                           \
 	"s_bitset1_b64 s[68:69], s80\n\t"                                                                                  \
@@ -655,6 +689,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
 	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
 	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"                                                                    \
+	CSNAPPY_TIMING_EXTRA_LOAD                                                                      \
 	"v_lshlrev_b32_e32 v48, 1, v49\n\t"                                                                                \
 	"global_load_ushort v42, v48, %[ids]\n\t"
 
@@ -672,7 +707,8 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
 	"s_add_u32 s92, %[epoch], -1\n\t"                  /* this step's epoch field */                                   \
 	"s_lshl_b32 s93, s92, 22\n\t"                                                                                      \
-	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes, and the table store of the step before */\
+	"s_waitcnt vmcnt(0)\n\t"                           /* the window, and the table store of the step before */        \
+	CSNAPPY_ISA_OWN_BYTES                                                                                              \
 	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
 	"v_lshrrev_b32_e32 v42, %[shift], v59\n\t"         /* my slot: the hash */                                         \
 	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of it */                             \
@@ -715,8 +751,10 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 
 #define CSNAPPY_ISA_LOADS_GTAB \
 	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
-	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
-	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"
+	"s_and_b32 s79, %[p0], -4\n\t"                     /* its window: aligned dwords from here, lane l takes dword l */\
+	"v_lshl_add_u32 v49, %[lane], 2, s79\n\t"                                                                          \
+	"v_min_u32_e32 v49, %[safemax4], v49\n\t"          /* (clamped: lanes >= 21 are not used, and the loads are harmless when the loop ends here) */\
+	"global_load_dword v44, v49, %[src]\n\t"
 
 #define CSNAPPY_ISA_COMMIT_GTAB \
 	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
@@ -762,35 +800,41 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_cndmask_b32_e64 v59, v58, v59, s[68:69]\n\t"                                                                    \
 	"s_add_u32 %[nemit], %[p0], s73\n\t"               /* next_emit: behind the last copy */                           \
 	"s_add_u32 s74, s73, 32\n\t"                                                                                       \
-	"v_max_u32_dpp v59, v59, v59 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_lshl_or_b32 v50, v34, 16, v40\n\t"              /* record: base | cand << 16 */                                 \
 	"s_min_u32 s74, s74, 63\n\t"                       /* e: the last lane the step probes */                          \
 	"s_add_u32 s75, s73, -1\n\t"                       /* c - 1 */                                                     \
-	"v_max_u32_dpp v59, v59, v59 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_add_u32_e32 v53, 1, v40\n\t"                                                                                    \
 	"s_sub_u32 s76, s74, s75\n\t"                      /* probes of the scan behind the copy: e - c + 1 */             \
 	"s_cmp_ge_u32 s73, 64\n\t"                         /* the copy leaves the step: re-match probe next */             \
-	"v_max_u32_dpp v59, v59, v59 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_cselect_b32 s75, s75, s74\n\t"                  /* lane 0 of the next step */                                   \
 	"s_cselect_b32 %[q1], 0, s76\n\t"                                                                                  \
-	"v_max_u32_dpp v59, v59, v59 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
 	"s_cselect_b32 s72, s72, s74\n\t"                  /* e_final: the last lane that is inserted */                   \
-	"s_mov_b64 vcc, s[68:69]\n\t"                                                                                      \
-	"v_max_u32_dpp v59, v59, v59 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
-	"v_mbcnt_lo_u32_b32 v48, vcc_lo, 0\n\t"                                                                            \
-	"v_mbcnt_hi_u32_b32 v48, vcc_hi, v48\n\t"          /* taken lanes below me */                                      \
-	"v_max_u32_dpp v59, v59, v59 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
-	"v_lshl_or_b32 v50, v34, 16, v40\n\t"              /* record: base | cand << 16 */                                 \
-	"v_add_u32_e32 v49, 1, v40\n\t"                                                                                    \
-	"v_mov_b32_dpp v58, v59 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* end of the nearest copy below me (none: next_emit) */ \
 	"s_add_u32 %[p0], %[p0], s75\n\t"                  /* pz */                                                        \
-	"v_add_lshl_u32 v48, v48, %[nev], 3\n\t"           /* my record's byte offset */                                   \
-	"s_add_u32 %[nev], %[nev], s78\n\t"                                                                                \
-	"v_lshl_or_b32 v51, v58, 16, v32\n\t"              /* record: copy_len | lit_start << 16 */                        \
-	"v_cmp_lt_u32_e64 s[70:71], v49, v58\n\t"          /* strictly inside a copy: never inserted */                    \
-	"v_cndmask_b32_e64 v43, %[norec], v48, s[68:69]\n\t"                                                               \
-	/* ---- 11: the cursor is known: the next step's loads, then this step's commit ---- */                         \
-	"11:\n\t"                                                                                                          \
+	/* ---- the cursor is known: the next step's loads go out first (the records and the commit run under them) ---- */\
 	GO                                                                                                                 \
 	LOADS                                                                                                              \
+	/* ---- records: the end of the nearest taken copy below every lane is the running maximum of the copies' ends ---- */\
+	"v_max_u32_dpp v59, v59, v59 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"s_mov_b64 vcc, s[68:69]\n\t"                                                                                      \
+	"v_mbcnt_lo_u32_b32 v48, vcc_lo, 0\n\t"                                                                            \
+	"v_max_u32_dpp v59, v59, v59 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_mbcnt_hi_u32_b32 v48, vcc_hi, v48\n\t"          /* taken lanes below me */                                      \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_max_u32_dpp v59, v59, v59 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_add_lshl_u32 v48, v48, %[nev], 3\n\t"           /* my record's byte offset */                                   \
+	"s_add_u32 %[nev], %[nev], s78\n\t"                                                                                \
+	"v_max_u32_dpp v59, v59, v59 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                             \
+	"v_cndmask_b32_e64 v43, %[norec], v48, s[68:69]\n\t"                                                               \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_max_u32_dpp v59, v59, v59 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                          \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_max_u32_dpp v59, v59, v59 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                          \
+	"s_nop 1\n\t"                                                                                                      \
+	"v_mov_b32_dpp v58, v59 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"/* end of the nearest copy below me (none: next_emit) */\
+	"v_lshl_or_b32 v51, v58, 16, v32\n\t"              /* record: copy_len | lit_start << 16 */                        \
+	"v_cmp_lt_u32_e64 s[70:71], v53, v58\n\t"          /* strictly inside a copy: never inserted */                    \
+	/* ---- 15: this step's commit ---- */                                                                             \
+	"15:\n\t"                                                                                                          \
 	COMMIT                                                                                                             \
 	"s_cmp_lt_u32 s82, 33\n\t"                                                                                         \
 	"s_cbranch_scc0 19f\n\t"                                                                                           \
@@ -1023,7 +1067,9 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_add_u32 %[q1], %[q1], s72\n\t"                                                                                  \
 	"s_add_u32 %[p0], %[p0], s72\n\t"                                                                                  \
 	"s_mov_b64 s[70:71], 0\n\t"                                                                                        \
-	"s_branch 11b\n\t"                                                                                                 \
+	GO                                                                                                                 \
+	LOADS                                                                                                              \
+	"s_branch 15b\n\t"                                                                                                 \
 	"19:\n\t"                                                                                                          \
 	"s_mov_b32 m0, s83\n\t"
 
@@ -1312,10 +1358,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		/* the step loop in ISA for the common case (CSNAPPY_ISA_LOOP above) */
 		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
 		constexpr bool FAST_G = CSNAPPY_FAST && GTAB && ORD && !PROF; /* the same loop around the global table */
-		/* a step is fast-eligible when it is dense (q1 <= 32) and pz + 64 < ip_limit: every lane is valid,
-		 * and so is every lane's p0 + lane + 16 < n */
+		/* a step is for the loop when it is dense (q1 <= 32) and pz + 68 < ip_limit: every lane is valid, so is
+		 * every lane's p0 + lane + 16 < n, and the 21 aligned dwords its window is loaded as end inside the fragment */
 		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
-		const uint32_t limit64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ip_limit > 64 ? ip_limit - 64 : 0u));
+		const uint32_t limit64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ip_limit > 68 ? ip_limit - 68 : 0u));
 
 		while (!fin && ++guard <= n) {
 			if constexpr (FAST) if (q1 <= 32 && pz < limit64) {
@@ -1328,10 +1374,11 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				uint32_t nemit = next_emit;
 				asm volatile(CSNAPPY_ISA_LOOP("", CSNAPPY_ISA_TABLE_DENSE, CSNAPPY_ISA_GO_DENSE, CSNAPPY_ISA_LOADS_DENSE,
 							      CSNAPPY_ISA_COMMIT_DENSE)
-					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0), "+v"(x1),
-					       "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0),
+					       "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
 					     : [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shift - 1), [mul] "s"(kHashMul),
-					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n), [lane] "v"(lane), [thr] "v"(thr),
+					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [safemax4] "s"(n - 4), [n] "s"(n), [lane] "v"(lane),
+					       [thr] "v"(thr),
 					       [norec] "v"(no_rec_off)
 					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v48", "v49", "v52", "v53",
 					       "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
@@ -1349,7 +1396,9 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				continue;
 			}
 			if constexpr (FAST_G) if (q1 <= 32 && pz < limit64 && epoch >= 2) {
-				register uint32_t x0 asm("v44") = raw0, x1 asm("v45") = raw1, x2 asm("v46") = raw2, x3 asm("v47") = raw3;
+				uint32_t w0;
+				__builtin_memcpy(&w0, src + min((pz & ~3u) + 4 * lane, n - 4), 4); /* the step's window as dwords (CSNAPPY_ISA_OWN_BYTES) */
+				register uint32_t x0 asm("v44") = w0;
 				register uint32_t vpos asm("v40") = pos;
 				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
 				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
@@ -1357,17 +1406,23 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				asm volatile(CSNAPPY_ISA_LOOP("s_mov_b64 s[60:61], -1\n\t", CSNAPPY_ISA_TABLE_GTAB, CSNAPPY_ISA_GO_GTAB,
 							      CSNAPPY_ISA_LOADS_GTAB, CSNAPPY_ISA_COMMIT_GTAB)
 					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), [epoch] "+s"(epoch),
-					       "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					       "+v"(x0), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
 					     : [src] "s"(src), [R] "s"(R), [gtab] "s"(gtab), [shm1] "s"(shift - 1), [shift] "s"(shift),
-					       [mul] "s"(kHashMul), [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n),
+					       [mul] "s"(kHashMul), [limit64] "s"(limit64), [safemax] "s"(n - 16), [safemax4] "s"(n - 4), [n] "s"(n),
 					       [smask] "s"(smask), [sbase] "s"(A.lds0), [zv] "s"(chk0 << 15), [lane] "v"(lane), [thr] "v"(thr),
 					       [norec] "v"(no_rec_off)
-					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v42", "v48", "v49", "v52",
+					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v42", "v45", "v46", "v47", "v48", "v49", "v52",
 					       "v53", "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65",
 					       "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",
 					       "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-					       "s92", "s93", "vcc", "scc", "memory");
-				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+					       "s92", "s93", "vcc", "scc", "memory",
+					       /* (v64 is not used: it makes this kernel declare more than 64 VGPRs, i.e. at most seven
+					        * waves on a SIMD.  With exactly 64 declared, the block using v60-v63 and eight waves
+					        * filling the SIMD's register file, waves read each other's values in those registers --
+					        * bit-exact with one wave per SIMD, wrong match lengths beside others; seven waves of 72
+					        * parse G_low as fast as eight of 64) */
+					       "v64");
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0));
 				next_emit = nemit;
 				prec = make_uint2(px, py);
 				prec_off = poff;
