@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development (GPU box): compress a generated workload on the GPU and print the first blocks whose bytes differ
-from the CPU checker's, with the first differing element of each.   usage: dbg_blocks.py [text|low|page] [MiB]"""
+from the CPU checker's, with the first differing element of each.   usage: tests/dbg_blocks.py [text|low|page] [MiB]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, oracle

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development (GPU box): the parser's records of one fragment, from two libraries, side by side.
-usage: dbg_records.py <libA> <libB> [workload] [MiB] [fragment]   (a library path, or 'default')"""
+usage: tests/dbg_records.py <libA> <libB> [workload] [MiB] [fragment]   (a library path, or 'default')"""
 import os, sys, subprocess, json
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
