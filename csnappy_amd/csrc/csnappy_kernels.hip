@@ -550,9 +550,14 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 		}
 	});
 	if (nb > A.dense_cap) {
+		/* (the spill-over table starts out like the table in LDS: every slot holds position 0's entry, the
+		 * reference's zeroed table seen through the check bit, parse_lean) */
+		uint32_t first4;
+		__builtin_memcpy(&first4, src, 4);
+		const uint32_t zv = (((first4 * kHashMul) >> (shift - 1)) & 1u) * 0x80008000u;
 		uint4 *z = reinterpret_cast<uint4 *>(F.region + A.spill_off);
 		for (uint32_t k = lane; k < (A.spill_cap * 2 + 15) / 16; k += 64)
-			z[k] = make_uint4(0, 0, 0, 0);
+			z[k] = make_uint4(zv, zv, zv, zv);
 	}
 	wave_lds_fence();
 	/* the ids (and the zeroed spill table) are read back by this wave only (same CU, same L1/L2
@@ -700,6 +705,123 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
 	"ds_write_b16 v36, v39\n\t"                        /* (of several with one slot the highest stays) */              \
 	"s_mov_b64 exec, -1\n\t"
+
+/* the dense table with a spill-over in HBM (parse_lean<TAB_LDS_DENSE, SPILL = true>): the buckets beyond the LDS
+ * table (ids >= dcap) keep their entries in a 4 KiB table behind the fragment's ids; s[94:95] = the lanes of such
+ * buckets, v35 (behind the walk) = their entries' offsets.  (Leaving the spill-over's stores in flight across the
+ * next step's first wait -- vmcnt(1) when one was issued -- was measured: 9.46 against 9.47 ms per GiB of compress on
+ * urls.10K, not kept.) */
+#define CSNAPPY_ISA_TABLE_SPILL \
+	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
+	"s_add_u32 s92, %[epoch], -1\n\t"                  /* (one epoch of the spilled lanes' filter per step) */         \
+	"s_lshl_b32 s93, %[epoch], 20\n\t"                                                                                 \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id, and the spill-over's stores of the step before */\
+	"v_cmp_le_u32_e64 s[94:95], %[dcap], v42\n\t"      /* lanes whose bucket lives in the spill-over table in HBM */   \
+	"v_cmp_ne_u32_e64 s[60:61], 0, v42\n\t"            /* lanes with a bucket */                                       \
+	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
+	"v_cndmask_b32_e64 v57, v42, 0, s[94:95]\n\t"      /* their LDS accesses go to the dummy entry */                  \
+	"v_lshlrev_b32_e32 v36, 1, v57\n\t"                /* my table entry */                                            \
+	"ds_read_u16 v56, v36\n\t"                                                                                         \
+	"v_and_b32_e32 v37, 0xfffc, v36\n\t"               /* its dword */                                                 \
+	"v_lshlrev_b32_e32 v58, 4, v57\n\t"                /* bits 4:0 = 16 * (id & 1) */                                  \
+	"v_lshlrev_b32_e64 v38, v58, 1\n\t"                /* 1 in my half */                                              \
+	"ds_add_rtn_u32 v57, v37, v38\n\t"                 /* comes back with the lower lanes' ones in it */               \
+	"v_writelane_b32 v41, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */\
+	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	"v_lshl_or_b32 v39, v59, 15, v40\n\t"              /* my entry, if I am inserted */                                \
+	"s_cmp_lg_u64 s[94:95], 0\n\t"                                                                                     \
+	"s_cbranch_scc0 50f\n\t"                                                                                           \
+	/* ---- some lanes' buckets live in HBM: their entries, and one filter among themselves (atomic minimum of
+	 * {epoch, id, lane} tags per key: the smallest id of a key settles it, lowest lane first) ---- */\
+	"v_subrev_u32_e32 v48, %[dcap], v42\n\t"                                                                           \
+	"v_lshl_or_b32 v53, v42, 7, %[lane]\n\t"                                                                           \
+	"v_and_b32_e32 v49, 127, v48\n\t"                  /* key */                                                       \
+	"v_or_b32_e32 v53, s93, v53\n\t"                   /* tag */                                                       \
+	"v_lshl_add_u32 v49, v49, 2, %[sbase]\n\t"                                                                         \
+	"v_lshlrev_b32_e32 v48, 1, v48\n\t"                                                                                \
+	"s_mov_b64 exec, s[94:95]\n\t"                                                                                     \
+	"ds_min_u32 v49, v53\n\t"                                                                                          \
+	"global_load_ushort v52, v48, %[spill]\n\t"        /* the entry */                                                 \
+	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	"s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                                \
+	"v_cndmask_b32_e64 v56, v56, v52, s[94:95]\n\t"                                                                    \
+	"ds_read_b32 v49, v49\n\t"                         /* what settled my key */                                       \
+	"50:\n\t"                                                                                                          \
+	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add, or the filter's read-back, may be on its way) */\
+	"v_xor_b32_e32 v59, v56, v39\n\t"                                                                                  \
+	"v_and_b32_e32 v34, 0x7fff, v56\n\t"                                                                               \
+	"v_cmp_lt_u32_e32 vcc, v59, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_and_b64 s[70:71], vcc, s[60:61]\n\t"            /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v59, 0, v34, s[70:71]\n\t"                                                                      \
+	"global_load_dwordx4 v[52:55], v59, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 v43, v[50:51], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_bfe_u32 v57, v57, v58, 16\n\t"                  /* my half as the add found it */                               \
+	"v_cmp_ne_u32_e32 vcc, v57, v56\n\t"               /* not the entry: a lower lane has my slot */                   \
+	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes (of the table in LDS) */                       \
+	"s_cmp_lg_u64 s[94:95], 0\n\t"                                                                                     \
+	"s_cbranch_scc0 51f\n\t"                                                                                           \
+	"v_bfe_u32 v57, v49, 7, 13\n\t"                    /* the id that settled my key */                                \
+	"v_and_b32_e32 v58, 127, v49\n\t"                  /* ... and its lowest lane */                                   \
+	"v_cmp_ne_u32_e64 s[88:89], v57, v42\n\t"          /* another id: flagged to be safe */                            \
+	"v_cmp_lt_u32_e32 vcc, v58, %[lane]\n\t"           /* mine, and a lower lane has it */                             \
+	"s_or_b64 vcc, vcc, s[88:89]\n\t"                                                                                  \
+	"s_and_b64 vcc, vcc, s[94:95]\n\t"                                                                                 \
+	"s_andn2_b64 vcc, vcc, 1\n\t"                      /* (lane 0 has no lower lane) */                                \
+	"s_andn2_b64 s[62:63], s[62:63], s[94:95]\n\t"                                                                     \
+	"s_or_b64 s[62:63], s[62:63], vcc\n\t"                                                                             \
+	"51:\n\t"                                                                                                          \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */
+
+#define CSNAPPY_ISA_GO_SPILL \
+	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
+	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */                          \
+	"s_cmp_lt_u32 s92, 2\n\t"                          /* ... unless the filter's epoch field runs out: the C++ step starts it over */\
+	"s_cselect_b32 s82, 99, s82\n\t"
+
+#define CSNAPPY_ISA_LOADS_SPILL \
+	"v_subrev_u32_e32 v35, %[dcap], v42\n\t"           /* (my entry's offset in the spill-over table, for the commit: the id is about to be overwritten) */\
+	"v_lshlrev_b32_e32 v35, 1, v35\n\t"                                                                                \
+	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"                                                                    \
+	"v_lshlrev_b32_e32 v48, 1, v49\n\t"                                                                                \
+	"global_load_ushort v42, v48, %[ids]\n\t"
+
+#define CSNAPPY_ISA_COMMIT_SPILL \
+	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
+	"ds_sub_u32 v37, v38\n\t"                          /* the adds are taken back */                                   \
+	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
+	"s_mov_b64 exec, s[70:71]\n\t"                                                                                     \
+	"ds_write_b16 v36, v39\n\t"                        /* (of several with one slot the highest stays; lanes of the spill-over write the dummy) */\
+	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	"s_and_b64 s[84:85], s[70:71], s[94:95]\n\t"       /* inserted lanes of the spill-over table */                    \
+	"s_cmp_eq_u64 s[84:85], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 43f\n\t"                                                                                           \
+	"s_and_b64 s[86:87], s[62:63], s[84:85]\n\t"       /* of several with one bucket only the highest may store (memory keeps no order) */\
+	"s_cmp_eq_u64 s[86:87], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 42f\n\t"                                                                                           \
+	"s_mov_b64 s[88:89], 0\n\t"                                                                                        \
+	"40:\n\t"                                                                                                          \
+	"s_flbit_i32_b64 s76, s[86:87]\n\t"                                                                                \
+	"s_xor_b32 s76, s76, 63\n\t"                                                                                       \
+	"v_readlane_b32 s77, v35, s76\n\t"                                                                                 \
+	"s_bfm_b64 s[90:91], s76, 0\n\t"                                                                                   \
+	"s_nop 0\n\t"                                                                                                      \
+	"v_cmp_eq_u32_e32 vcc, s77, v35\n\t"                                                                               \
+	"s_and_b64 vcc, vcc, s[84:85]\n\t"                                                                                 \
+	"s_andn2_b64 s[86:87], s[86:87], vcc\n\t"                                                                          \
+	"s_and_b64 vcc, vcc, s[90:91]\n\t"                                                                                 \
+	"s_or_b64 s[88:89], s[88:89], vcc\n\t"                                                                             \
+	"s_cmp_lg_u64 s[86:87], 0\n\t"                                                                                     \
+	"s_cbranch_scc1 40b\n\t"                                                                                           \
+	"s_andn2_b64 s[84:85], s[84:85], s[88:89]\n\t"                                                                     \
+	"42:\n\t"                                                                                                          \
+	"s_mov_b64 exec, s[84:85]\n\t"                                                                                     \
+	"global_store_short v35, v39, %[spill]\n\t"                                                                        \
+	"s_mov_b64 exec, -1\n\t"                                                                                           \
+	"43:\n\t"                                                                                                          \
+	"s_mov_b32 %[epoch], s92\n\t"
 
 /* the full 2^p-byte table in global memory, an occupancy bitmap and the keyed exchange array in LDS
  * (parse_lean<TAB_GLOBAL>): the slot is the hash; v36 = my entry's offset, v37 = my bitmap word, v38 = my bit */
@@ -1148,7 +1270,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 	 * differs cannot match and is not gathered).  memset(table, 0), csnappy_compress.c:501, makes an
 	 * empty slot mean position 0; the LDS tables (TW, no spill-over) are filled with position 0's entry
 	 * instead, so that a lane need not tell an empty slot from a written one. */
-	constexpr bool CHK0_INIT = TW && !SPILL;
+	constexpr bool CHK0_INIT = TW;
 	uint32_t chk0 = 0;
 	if (n >= 4) {
 		uint32_t first4;
@@ -1358,6 +1480,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		/* the step loop in ISA for the common case (CSNAPPY_ISA_LOOP above) */
 		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
 		constexpr bool FAST_G = CSNAPPY_FAST && GTAB && ORD && !PROF; /* the same loop around the global table */
+		constexpr bool FAST_S = CSNAPPY_FAST && DENSE && SPILL && ORD && !PROF; /* ... and around the dense table with a spill-over */
 		/* a step is for the loop when it is dense (q1 <= 32) and pz + 68 < ip_limit: every lane is valid, so is
 		 * every lane's p0 + lane + 16 < n, and the 21 aligned dwords its window is loaded as end inside the fragment */
 		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
@@ -1387,6 +1510,33 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					       "scc", "memory");
 				/* (the loads its last step requested are still on their way: clamped addresses, nobody
 				 * wants them) */
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
+				next_emit = nemit;
+				prec = make_uint2(px, py);
+				prec_off = poff;
+				fin = pz + 1 >= ip_limit;
+				place();
+				continue;
+			}
+			if constexpr (FAST_S) if (q1 <= 32 && pz < limit64 && epoch >= 2) {
+				register uint32_t x0 asm("v44") = raw0, x1 asm("v45") = raw1, x2 asm("v46") = raw2, x3 asm("v47") = raw3;
+				register uint32_t vsid asm("v42") = sid, vpos asm("v40") = pos;
+				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
+				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
+				uint32_t nemit = next_emit;
+				asm volatile(CSNAPPY_ISA_LOOP("", CSNAPPY_ISA_TABLE_SPILL, CSNAPPY_ISA_GO_SPILL, CSNAPPY_ISA_LOADS_SPILL,
+							      CSNAPPY_ISA_COMMIT_SPILL)
+					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), [epoch] "+s"(epoch),
+					       "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					     : [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [spill] "s"(spill), [shm1] "s"(shift - 1),
+					       [mul] "s"(kHashMul), [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n),
+					       [dcap] "s"(dense_cap), [sbase] "s"(2 * dense_cap), [lane] "v"(lane), [thr] "v"(thr),
+					       [norec] "v"(no_rec_off)
+					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v48", "v49", "v52", "v53",
+					       "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+					       "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+					       "s93", "s94", "s95", "vcc", "scc", "memory");
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
 				next_emit = nemit;
 				prec = make_uint2(px, py);
