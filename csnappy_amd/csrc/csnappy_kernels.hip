@@ -92,6 +92,7 @@ struct CompressArgs {
 	uint32_t max_in_len; /* the caller's bound on in_len[]: a longer block is refused (out_len = 0xffffffff) */
 	uint32_t emit_wave_per_block, emit_blocks; /* emit: one wave per block (fpb == 1, small blocks) */
 	uint32_t sample_min;    /* TAB_LDS_DENSE: full fragments with fewer distinct sampled hashes go to TAB_GLOBAL */
+	uint32_t no_isa;        /* 1: every step takes parse_lean's C++ (CSNAPPY_HIP_NO_ISA=1; the hand-written loops' reference) */
 	int p;
 	int mode;
 };
@@ -1484,7 +1485,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		/* a step is for the loop when it is dense (q1 <= 32) and pz + 68 < ip_limit: every lane is valid, so is
 		 * every lane's p0 + lane + 16 < n, and the 21 aligned dwords its window is loaded as end inside the fragment */
 		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
-		const uint32_t limit64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ip_limit > 68 ? ip_limit - 68 : 0u));
+		const uint32_t limit64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ip_limit > 68 && !A.no_isa ? ip_limit - 68 : 0u));
 
 		while (!fin && ++guard <= n) {
 			if constexpr (FAST) if (q1 <= 32 && pz < limit64) {
@@ -4059,11 +4060,14 @@ uint32_t record_cap(uint32_t n)
  *                                                         LDS table takes such fragments instead)
  *   CSNAPPY_HIP_NO_LDS_ORDER 0..1                         1: the parsers that do not rely on the order in which
  *                                                         the LDS serves one instruction's lanes (the ones a
- *                                                         device that fails snappy_lds_order_probe gets) */
+ *                                                         device that fails snappy_lds_order_probe gets)
+ *   CSNAPPY_HIP_NO_ISA     0..1                           1: no hand-written step loop: every step takes parse_lean's
+ *                                                         compiled C++ (the loops' reference; same bytes, ~10 % slower) */
 struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
 	uint32_t no_lds_order; /* 1: take the ORD = false parsers whatever the probe says */
+	uint32_t no_isa;       /* 1: the compiled step loop for every step */
 	bool ok;
 };
 
@@ -4082,7 +4086,7 @@ bool knob_u32(const char *name, uint32_t lo, uint32_t hi, uint32_t *out)
 
 Knobs read_knobs()
 {
-	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, 0, true };
+	Knobs k = { -1, 0, 0, 0, kSampleMinDefault, kSpillCapDefault, 0, 0, true };
 	if (const char *e = getenv("CSNAPPY_HIP_TABLE")) {
 		if (!strcmp(e, "hash"))
 			k.table = TAB_LDS_HASH;
@@ -4100,6 +4104,7 @@ Knobs read_knobs()
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_WGS_PER_CU", 1, 32, &k.wgs_per_cu);
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_SAMPLE_MIN", 0, 2048, &k.sample_min);
 	k.ok = k.ok && knob_u32("CSNAPPY_HIP_NO_LDS_ORDER", 0, 1, &k.no_lds_order);
+	k.ok = k.ok && knob_u32("CSNAPPY_HIP_NO_ISA", 0, 1, &k.no_isa);
 	return k;
 }
 
@@ -4471,6 +4476,7 @@ int csnappy_hip_compress_batch(const void *d_in, const uint64_t *d_in_off, const
 	A.spill_off = W.tab_stride - P.spill_cap * 2;
 	A.max_in_len = max_in_len;
 	A.sample_min = P.sample_min;
+	A.no_isa = kn.no_isa;
 	A.p = p;
 	A.mode = mode;
 

@@ -891,6 +891,27 @@ def test_every_placement_without_the_lds_order(torch, chk, placement, monkeypatc
     assert sha(b"".join(blocks)) == g["sha256"]
 
 
+@pytest.mark.parametrize("placement", ["dense", "global", "dense-cap1024-spill6144"])
+def test_the_compiled_step_loop_behind_the_hand_written_ones(torch, chk, placement, monkeypatch):
+    """The dense, spill-over and global-table parsers run their steps in hand-written ISA loops; parse_lean's C++
+    states the same logic and takes the steps the loops leave to it (sparse steps, fragment tails).  With
+    CSNAPPY_HIP_NO_ISA=1 it takes every step: the same bytes."""
+    monkeypatch.setenv("CSNAPPY_HIP_NO_ISA", "1")
+    _force_placement(monkeypatch, placement)
+    xs = list(_ragged_cases(902, 24)) + list(_slot_sharing_cases(79, 25))
+    for p, mode in ((16, api.STREAM), (15, api.FRAGMENT)):
+        ys = [x[:32768] for x in xs] if mode == api.FRAGMENT else xs
+        host, lens = np.concatenate(ys), [len(y) for y in ys]
+        blocks, _, _ = gpu_compress(torch, host, lens, p, mode)
+        want = oracle_blocks(chk, host, lens, p, mode)
+        bad = [i for i, (a, b) in enumerate(zip(blocks, want)) if a != b]
+        assert not bad, (placement, p, mode, bad[:5], [lens[i] for i in bad[:5]])
+    g = GOLD["workloads"]["G_text_64k_p16"]
+    d_in = api.generate(g["kind"], g["seed"], 0, g["nblocks"], g["block"])
+    blocks, _, _ = gpu_compress(torch, d_in.cpu().numpy(), [g["block"]] * g["nblocks"], g["p"], g["mode"])
+    assert sha(b"".join(blocks)) == g["sha256"]
+
+
 def test_block_longer_than_promised_is_refused_not_corrupted(torch, chk):
     """in_len[b] > max_in_len violates the batch call's precondition (the workspace is sized by
     max_in_len): that block gets out_len = 0xffffffff and its slot is not touched, its neighbours are
