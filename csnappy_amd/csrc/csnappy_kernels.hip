@@ -595,9 +595,14 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  * vector-written SGPR at once.
  *
  * Registers are fixed (named as clobbers, or bound to register variables where C++ hands values in
- * and out).  v59 is the highest: the global-table kernel then declares 60 VGPRs -- with 64, the top four
- * in use and eight waves on a SIMD (every VGPR of the SIMD allocated), waves read each other's values
- * there (found the hard way: bit-exact with one wave per SIMD, wrong match lengths beside others).
+ * and out).  v59 is the highest, for a reason that is not understood: a build of the global-table kernel
+ * that declared exactly 64 VGPRs with this block using v60-v63 was bit-exact with one workgroup per CU
+ * and computed wrong match lengths beside others (the extension's shift amounts, which lived in v62 /
+ * v63: every fragment behind the first four per CU, every run); with the map ended at v59 (60 declared) or
+ * with more than 64 declared it is exact, and so has every build since.  A stand-alone kernel that keeps
+ * values in v60-v63 of a 64-VGPR allocation at 32 waves per CU reads them back intact
+ * (tools/ubench/vgpr_top.hip, a billion read-backs), so it is not simply "the top registers alias";
+ * tests/test_isa_hazards.py pins both precautions.
  *   v32 mlen   v33 cl   v34 cand   v35 nx   v36 entry address   v37 its dword   v38 my 1   v39 my entry
  *   v40 pos    v41 probes left per lane (32; lane 0: what is left of the scan)   v42 id / slot   v43 record offset
  *   v44-v47 own 16 bytes   v48-v49, v52-v59 scratch   v50-v51 the step's record
@@ -1567,11 +1572,10 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					       "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",
 					       "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
 					       "s92", "s93", "vcc", "scc", "memory",
-					       /* (v64 is not used: it makes this kernel declare more than 64 VGPRs, i.e. at most seven
-					        * waves on a SIMD.  With exactly 64 declared, the block using v60-v63 and eight waves
-					        * filling the SIMD's register file, waves read each other's values in those registers --
-					        * bit-exact with one wave per SIMD, wrong match lengths beside others; seven waves of 72
-					        * parse G_low as fast as eight of 64) */
+					       /* (v64 is not used: it makes this kernel declare more than 64 VGPRs.  A build that declared
+					        * exactly 64, with the block using v60-v63, computed wrong match lengths whenever other
+					        * workgroups shared its CU -- see "Registers are fixed" at CSNAPPY_ISA_LOOP; its SGPR count
+					        * holds this kernel to seven waves a SIMD anyway, and seven of 72 parse G_low as fast) */
 					       "v64");
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0));
 				next_emit = nemit;
