@@ -599,10 +599,12 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  * that declared exactly 64 VGPRs with this block using v60-v63 was bit-exact with one workgroup per CU
  * and computed wrong match lengths beside others (the extension's shift amounts, which lived in v62 /
  * v63: every fragment behind the first four per CU, every run); with the map ended at v59 (60 declared) or
- * with more than 64 declared it is exact, and so has every build since.  A stand-alone kernel that keeps
- * values in v60-v63 of a 64-VGPR allocation at 32 waves per CU reads them back intact
- * (tools/ubench/vgpr_top.hip, a billion read-backs), so it is not simply "the top registers alias";
- * tests/test_isa_hazards.py pins both precautions.
+ * with more than 64 declared it is exact, and so has every build since.  It reproduces on demand (the map
+ * moved up by four again: blocks 512.. of 64 MiB of G_low wrong, every run), it is not the register count
+ * (the same build with v60-v63 and v36-v39 exchanged -- the match lengths, ends, candidates and next stops up
+ * there, the temporaries down here -- is exact at 64 VGPRs), and a stand-alone kernel that computes in,
+ * loads into and reads back v60-v63 of a 64-VGPR allocation at 32 waves per CU finds nothing
+ * (tools/ubench/vgpr_top.hip, a billion read-backs).  tests/test_isa_hazards.py pins both precautions.
  *   v32 mlen   v33 cl   v34 cand   v35 nx   v36 entry address   v37 its dword   v38 my 1   v39 my entry
  *   v40 pos    v41 probes left per lane (32; lane 0: what is left of the scan)   v42 id / slot   v43 record offset
  *   v44-v47 own 16 bytes   v48-v49, v52-v59 scratch   v50-v51 the step's record

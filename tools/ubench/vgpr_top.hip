@@ -10,7 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-template <int TOP> __global__ void __launch_bounds__(64) k_top(uint32_t *bad, const uint32_t *in, uint32_t *out, uint32_t rounds)
+template <int TOP, int MEM> __global__ void __launch_bounds__(64) k_top(uint32_t *bad, const uint32_t *in, uint32_t *out, uint32_t rounds)
 {
 	extern __shared__ uint32_t lds[];
 	const uint32_t lane = threadIdx.x, w = blockIdx.x;
@@ -32,6 +32,21 @@ template <int TOP> __global__ void __launch_bounds__(64) k_top(uint32_t *bad, co
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			acc = acc * 33 + lds[(lane + k) & 63];
 		}
+		/* ... and the same registers as the destination of memory instructions: a 16-byte global load and an LDS
+		 * read that return while the other waves of the SIMD run */
+		if (MEM) {
+			const uint32_t off = (tag * 16 + r * 64) & 0xffff0;
+			if (TOP)
+				asm volatile("global_load_dwordx4 v[60:63], %0, %1\n\ts_waitcnt vmcnt(0)\n\t"
+					     "v_sub_u32 v60, v60, v61\n\tv_sub_u32 v62, v62, v63\n\tv_or_b32 v60, v60, v62\n\t"
+					     "v_add_u32 v60, v60, %2\n\tv_add_u32 v61, 1, %2\n\tv_add_u32 v62, 2, %2\n\tv_add_u32 v63, 3, %2"
+					     : : "v"(off), "s"(in), "v"(v) : "v60", "v61", "v62", "v63", "memory");
+			else
+				asm volatile("global_load_dwordx4 v[52:55], %0, %1\n\ts_waitcnt vmcnt(0)\n\t"
+					     "v_sub_u32 v52, v52, v53\n\tv_sub_u32 v54, v54, v55\n\tv_or_b32 v52, v52, v54\n\t"
+					     "v_add_u32 v52, v52, %2\n\tv_add_u32 v53, 1, %2\n\tv_add_u32 v54, 2, %2\n\tv_add_u32 v55, 3, %2"
+					     : : "v"(off), "s"(in), "v"(v) : "v52", "v53", "v54", "v55", "v63", "memory");
+		}
 		uint32_t a, b, c, d;
 		if (TOP)
 			asm volatile("v_mov_b32 %0, v60\n\tv_mov_b32 %1, v61\n\tv_mov_b32 %2, v62\n\tv_mov_b32 %3, v63"
@@ -52,21 +67,24 @@ int main()
 	hipMalloc(&bad, 4);
 	hipMalloc(&in, 4 << 20);
 	hipMalloc(&out, 4 * 64 * 65536);
-	hipMemset(in, 1, 4 << 20);
+	hipMemset(in, 1, 4 << 20); /* (every dword 0x01010101: the loaded registers cancel out) */
 	hipFuncAttributes fa;
-	for (int top = 0; top < 2; ++top) {
-		hipFuncGetAttributes(&fa, top ? (const void *)k_top<1> : (const void *)k_top<0>);
-		for (uint32_t lds_bytes : { 5120u, 40960u }) { /* 32 waves a CU / 4 */
-			hipMemset(bad, 0, 4);
-			if (top)
-				hipLaunchKernelGGL(k_top<1>, dim3(65536), dim3(64), lds_bytes, 0, bad, in, out, 64u);
-			else
-				hipLaunchKernelGGL(k_top<0>, dim3(65536), dim3(64), lds_bytes, 0, bad, in, out, 64u);
-			hipDeviceSynchronize();
-			hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
-			printf("%s registers, %d VGPRs declared, %5u B of LDS a workgroup: %u wrong read-backs of %u\n",
-			       top ? "v60-v63" : "v52-v55", fa.numRegs, lds_bytes, h, 65536u * 64 * 64 * 4);
+	for (int mem = 0; mem < 2; ++mem)
+		for (int top = 0; top < 2; ++top) {
+			const void *k = mem ? (top ? (const void *)k_top<1, 1> : (const void *)k_top<0, 1>)
+					    : (top ? (const void *)k_top<1, 0> : (const void *)k_top<0, 0>);
+			hipFuncGetAttributes(&fa, k);
+			for (uint32_t lds_bytes : { 5120u, 40960u }) { /* 32 waves a CU / 4 */
+				hipMemset(bad, 0, 4);
+				uint32_t rounds = 64;
+				void *args[] = { &bad, &in, &out, &rounds };
+				hipLaunchKernel(k, dim3(65536), dim3(64), args, lds_bytes, 0);
+				hipDeviceSynchronize();
+				hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+				printf("%s registers%s, %d VGPRs declared, %5u B of LDS a workgroup: %u wrong read-backs of %u\n",
+				       top ? "v60-v63" : "v52-v55", mem ? " (also loaded into)" : "", fa.numRegs, lds_bytes, h,
+				       65536u * 64 * 64 * 4);
+			}
 		}
-	}
 	return 0;
 }
