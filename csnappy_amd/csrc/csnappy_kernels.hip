@@ -714,6 +714,40 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"ds_write_b16 v36, v39\n\t"                        /* (of several with one slot the highest stays) */              \
 	"s_mov_b64 exec, -1\n\t"
 
+/* the table in LDS indexed by the hash itself (parse_lean<TAB_LDS_HASH>: tables of <= 8 KiB, no prologue): every lane
+ * has a slot, s[60:61] = all lanes; the test for another round and the commit are the dense table's */
+#define CSNAPPY_ISA_TABLE_HASH \
+	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
+	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes */                                                 \
+	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
+	"v_lshrrev_b32_e32 v42, %[shift], v59\n\t"         /* my slot: the hash (every lane has one) */                    \
+	"v_lshlrev_b32_e32 v36, 1, v42\n\t"                /* my table entry */                                            \
+	"ds_read_u16 v56, v36\n\t"                                                                                         \
+	"v_and_b32_e32 v37, 0xfffc, v36\n\t"               /* its dword */                                                 \
+	"v_lshlrev_b32_e32 v58, 4, v42\n\t"                /* bits 4:0 = 16 * (slot & 1) */                                \
+	"v_lshlrev_b32_e64 v38, v58, 1\n\t"                /* 1 in my half */                                              \
+	"ds_add_rtn_u32 v57, v37, v38\n\t"                 /* comes back with the lower lanes' ones in it */               \
+	"v_writelane_b32 v41, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */\
+	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	"v_lshl_or_b32 v39, v59, 15, v40\n\t"              /* my entry, if I am inserted */                                \
+	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
+	"v_xor_b32_e32 v59, v56, v39\n\t"                                                                                  \
+	"v_and_b32_e32 v34, 0x7fff, v56\n\t"                                                                               \
+	"v_cmp_lt_u32_e32 vcc, v59, %[thr]\n\t"            /* check bits agree (thr: 0x8000; lane 0, insert-only: 0) */    \
+	"s_mov_b64 s[70:71], vcc\n\t"                      /* the candidate can match at all */                            \
+	"v_cndmask_b32_e64 v59, 0, v34, s[70:71]\n\t"                                                                      \
+	"global_load_dwordx4 v[52:55], v59, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
+	"global_store_dwordx2 v43, v[50:51], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_bfe_u32 v57, v57, v58, 16\n\t"                  /* my half as the add found it */                               \
+	"v_cmp_ne_u32_e64 s[62:63], v57, v56\n\t"          /* flagged: not the entry, a lower lane has my slot */          \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */
+
+#define CSNAPPY_ISA_LOADS_HASH \
+	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"
+
 /* the dense table with a spill-over in HBM (parse_lean<TAB_LDS_DENSE, SPILL = true>): the buckets beyond the LDS
  * table (ids >= dcap) keep their entries in a 4 KiB table behind the fragment's ids; s[94:95] = the lanes of such
  * buckets, v35 (behind the walk) = their entries' offsets.  (Leaving the spill-over's stores in flight across the
@@ -1489,6 +1523,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 		constexpr bool FAST = CSNAPPY_FAST && DENSE && !SPILL && ORD && !PROF;
 		constexpr bool FAST_G = CSNAPPY_FAST && GTAB && ORD && !PROF; /* the same loop around the global table */
 		constexpr bool FAST_S = CSNAPPY_FAST && DENSE && SPILL && ORD && !PROF; /* ... and around the dense table with a spill-over */
+		constexpr bool FAST_H = CSNAPPY_FAST && TAB == TAB_LDS_HASH && ORD && !PROF; /* ... and the table indexed by the hash */
 		/* a step is for the loop when it is dense (q1 <= 32) and pz + 68 < ip_limit: every lane is valid, so is
 		 * every lane's p0 + lane + 16 < n, and the 21 aligned dwords its window is loaded as end inside the fragment */
 		/* (readfirstlane: the compiler computes the saturating subtraction on the vector unit) */
@@ -1546,6 +1581,32 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
 					       "s93", "s94", "s95", "vcc", "scc", "memory");
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
+				next_emit = nemit;
+				prec = make_uint2(px, py);
+				prec_off = poff;
+				fin = pz + 1 >= ip_limit;
+				place();
+				continue;
+			}
+			if constexpr (FAST_H) if (q1 <= 32 && pz < limit64) {
+				register uint32_t x0 asm("v44") = raw0, x1 asm("v45") = raw1, x2 asm("v46") = raw2, x3 asm("v47") = raw3;
+				register uint32_t vpos asm("v40") = pos;
+				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
+				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
+				uint32_t nemit = next_emit;
+				asm volatile(CSNAPPY_ISA_LOOP("s_mov_b64 s[60:61], -1\n\t", CSNAPPY_ISA_TABLE_HASH, CSNAPPY_ISA_GO_DENSE,
+							      CSNAPPY_ISA_LOADS_HASH, CSNAPPY_ISA_COMMIT_DENSE)
+					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0), "+v"(x1),
+					       "+v"(x2), "+v"(x3), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					     : [src] "s"(src), [R] "s"(R), [shm1] "s"(shift - 1), [shift] "s"(shift), [mul] "s"(kHashMul),
+					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [n] "s"(n), [lane] "v"(lane), [thr] "v"(thr),
+					       [norec] "v"(no_rec_off)
+					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v42", "v48", "v49", "v52",
+					       "v53", "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65",
+					       "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",
+					       "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+					       "vcc", "scc", "memory");
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 				next_emit = nemit;
 				prec = make_uint2(px, py);
 				prec_off = poff;

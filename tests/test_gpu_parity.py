@@ -891,7 +891,7 @@ def test_every_placement_without_the_lds_order(torch, chk, placement, monkeypatc
     assert sha(b"".join(blocks)) == g["sha256"]
 
 
-@pytest.mark.parametrize("placement", ["dense", "global", "dense-cap1024-spill6144"])
+@pytest.mark.parametrize("placement", ["dense", "hash", "global", "dense-cap1024-spill6144"])
 def test_the_compiled_step_loop_behind_the_hand_written_ones(torch, chk, placement, monkeypatch):
     """The dense, spill-over and global-table parsers run their steps in hand-written ISA loops; parse_lean's C++
     states the same logic and takes the steps the loops leave to it (sparse steps, fragment tails).  With
