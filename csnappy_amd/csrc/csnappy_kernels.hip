@@ -2130,6 +2130,8 @@ DEVINL RecFields decode_record(uint2 r, bool live)
 struct ChunkIn {
 	uint2 r;     /* the lane's record */
 	uint4 la, lb; /* 32 bytes at the record's literal (small records only) */
+	uint32_t mw; /* dword `lane` of the literal of the chunk's first record with a literal of up to kMediumLiteral bytes
+		      * that is not small (round 6: fetched with the chunk, not when its turn comes) */
 };
 
 DEVINL bool record_is_small(const RecFields &f, bool live, uint32_t avail)
@@ -2145,14 +2147,31 @@ DEVINL uint2 fetch_record(const uint2 *R, uint32_t first, uint32_t nev, uint32_t
 	return lane < nev ? R[first + lane] : make_uint2(0, 0);
 }
 
+/* the record whose literal travels in ChunkIn::mw: not small, a literal of 1..kMediumLiteral bytes */
+DEVINL bool record_has_wide_literal(const RecFields &f, bool live, uint32_t avail)
+{
+	return live && !record_is_small(f, live, avail) && f.lit_len && f.lit_len <= kMediumLiteral;
+}
+
 DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t avail, uint32_t lane)
 {
 	const bool live = lane < nev;
 	const RecFields f = decode_record(c.r, live);
 	c.la = c.lb = make_uint4(0, 0, 0, 0);
+	c.mw = 0;
 	if (record_is_small(f, live, avail) && f.lit_len) {
 		__builtin_memcpy(&c.la, src + f.lit_start, 16);
 		__builtin_memcpy(&c.lb, src + f.lit_start + 16, 16);
+	}
+	/* A literal of 32..256 bytes (text: one record in 150, one chunk in three) used to be fetched where it
+	 * is staged: a memory round trip in the middle of the chunk, a fifth of the kernel's time.  Its bytes are
+	 * one dword per lane: requested here, a chunk ahead, with the others'. */
+	const uint64_t wide = ballot64(record_has_wide_literal(f, live, avail));
+	if (wide) {
+		const uint32_t m = first_lane(wide);
+		const uint32_t ls = rdlane(f.lit_start, m), ll = rdlane(f.lit_len, m);
+		if (4 * lane < ll && ls + 4 * lane + 4 <= avail)
+			__builtin_memcpy(&c.mw, src + ls + 4 * lane, 4);
 	}
 }
 
@@ -2161,6 +2180,9 @@ DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t
  * also sit out their round trip) */
 #ifndef CSNAPPY_EMIT_NOBIG
 #define CSNAPPY_EMIT_NOBIG 0
+#endif
+#ifndef CSNAPPY_EMIT_EXP
+#define CSNAPPY_EMIT_EXP 0
 #endif
 #ifndef CSNAPPY_EMIT_PROF
 #define CSNAPPY_EMIT_PROF 0
@@ -2197,7 +2219,7 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	auto drain = [&]() {
 		wave_lds_fence();
 		asm volatile("" : "+v"(ahead.r.x), "+v"(ahead.r.y), "+v"(ahead.la.x), "+v"(ahead.la.y), "+v"(ahead.la.z),
-			     "+v"(ahead.la.w), "+v"(ahead.lb.x), "+v"(ahead.lb.y), "+v"(ahead.lb.z), "+v"(ahead.lb.w));
+			     "+v"(ahead.la.w), "+v"(ahead.lb.x), "+v"(ahead.lb.y), "+v"(ahead.lb.z), "+v"(ahead.lb.w), "+v"(ahead.mw));
 		uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
 		const uint32_t end = sa + fill;
 		uint32_t first_full = 0;
@@ -2263,25 +2285,47 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 				/* (left = the lane's payload bytes still to store; kept opaque to the compiler, which
 				 * otherwise computes the eight rounds' lane masks up front and spills them) */
 				uint32_t left = in_run && small ? lit_len_ : 0;
+#if CSNAPPY_EMIT_EXP & 4 /* timing experiment only (wrong output): no payload stores */
+				left = 0;
+#endif
 #pragma unroll
 				for (uint32_t k = 0; k < 8; ++k) {
 					asm volatile("" : "+v"(left));
 					if (!ballot64(left > 4 * k))
 						break;
+#if CSNAPPY_EMIT_EXP & 2 /* timing experiment only (wrong output): aligned dword stores */
+					if (left > 4 * k)
+						*reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(o + lhdr_ + 4 * k) & ~(uintptr_t)3) = lw[k];
+#else
 					if (left > 4 * k)
 						__builtin_memcpy(o + lhdr_ + 4 * k, &lw[k], 4);
+#endif
 				}
 			}
 			wave_lds_fence();
 			{
 				const uint64_t run_mask = (seg_hi < 64 ? (1ull << seg_hi) - 1 : ~0ull) & ~((1ull << seg_lo) - 1);
 				uint64_t mm = medmask & run_mask;
+#if CSNAPPY_EMIT_EXP & 1 /* timing experiment only (wrong output): no medium literals */
+				mm = 0;
+#endif
 				if (mm) {
+					/* (the literal that came with the chunk: its first record with such a literal, whole dwords inside the input) */
+					const uint64_t wide = ballot64(record_has_wide_literal(f, live, avail));
+					const uint32_t wm = wide ? first_lane(wide) : 64u;
 					do {
 						const uint32_t m = first_lane(mm);
 						mm &= mm - 1;
 						const uint32_t ls = rdlane(lit_start, m), ll = rdlane(lit_len_, m);
 						uint8_t *pd = stage + sa + fill + (rdlane(excl, m) - run_base) + rdlane(lhdr_, m);
+						/* (whole dwords, like the small records' payload above: the up to three bytes past the
+						 * literal land on the record's own copy tag and the next record's first byte, a header
+						 * or a tag, all written below -- so only for a record that has a copy) */
+						if (m == wm && ls + ((ll + 3) & ~3u) <= avail && rdlane(clen_, m)) {
+							if (4 * lane < ll)
+								__builtin_memcpy(pd + 4 * lane, &in.mw, 4);
+							continue;
+						}
 						for (uint32_t j = 4 * lane; j < ll; j += 256) {
 							if (j + 4 <= ll) {
 								uint32_t w;
