@@ -540,9 +540,15 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 			id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
 		}
 		if (cntp == 8) {
+#if CSNAPPY_NT & 1 /* experiment: the ids leave the caches behind them */
+			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+			const u32x4 pk = { id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16), id[6] | (id[7] << 16) };
+			__builtin_nontemporal_store(pk, reinterpret_cast<u32x4 *>(wids + i));
+#else
 			*reinterpret_cast<uint4 *>(wids + i) =
 				make_uint4(id[0] | (id[1] << 16), id[2] | (id[3] << 16), id[4] | (id[5] << 16),
 					   id[6] | (id[7] << 16));
+#endif
 		} else {
 #pragma unroll
 			for (uint32_t k = 0; k < 7; ++k)
@@ -612,6 +618,37 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  *   s[70:71] candidate can match / inside a copy   s72-s79, s84-s91 scratch   s80 t   s81 lim0   s82 go
  *   s83 the compiler's m0   s92-s93 the global table's epoch field
  * ======================================================================================== */
+#ifndef CSNAPPY_NT
+#define CSNAPPY_NT 0 /* experiments: streaming hints (1: the prologue's id stores, 2: the records' stores, 4: the id loads) */
+#endif
+#if CSNAPPY_NT & 2
+#define CSNAPPY_NT_REC " nt"
+#else
+#define CSNAPPY_NT_REC ""
+#endif
+#if CSNAPPY_NT & 4
+#define CSNAPPY_NT_IDL " nt"
+#else
+#define CSNAPPY_NT_IDL ""
+#endif
+#ifndef CSNAPPY_ISA_PROF
+#define CSNAPPY_ISA_PROF 0
+#endif
+#if CSNAPPY_ISA_PROF
+/* development builds only (tools/build_variant.sh <name> -DCSNAPPY_ISA_PROF=1, tools/phase_isa.py): the dense loop's phases
+ * by s_memtime, summed per wave in v65.. (every stamp costs a scalar-memory round trip of its own: the same for every phase) */
+__device__ unsigned long long g_isa_prof[16];
+#define CSNAPPY_ISA_P(r) "s_memtime s[96:97]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s98, s96, s99\n\ts_mov_b32 s99, s96\n\tv_add_u32_e32 " r ", s98, " r "\n\t"
+#define CSNAPPY_ISA_P0 "s_memtime s[96:97]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s99, s96\n\t"
+#define CSNAPPY_ISA_PSTEP "v_add_u32_e32 v71, 1, v71\n\t"
+#else
+#define CSNAPPY_ISA_PSTEP ""
+#define CSNAPPY_ISA_P(r) ""
+#define CSNAPPY_ISA_P0 ""
+#endif
+#ifndef CSNAPPY_DENSE_WINDOW
+#define CSNAPPY_DENSE_WINDOW 0 /* 1: the dense loop takes its own bytes and ids out of a window requested a step ahead (A/B: no gain) */
+#endif
 #if CSNAPPY_TIMING_TA == 1 /* timing experiment: one more 16-byte-per-lane load per step (is the texture addresser the bound?) */
 #define CSNAPPY_TIMING_EXTRA_LOAD "global_load_dwordx4 v[44:47], v49, %[src]\n\t"
 #elif CSNAPPY_TIMING_TA == 2 /* ... or eight more vector instructions */
@@ -643,13 +680,29 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_alignbyte_b32 v46, v57, v56, v59\n\t"                                                                           \
 	"v_alignbyte_b32 v47, v58, v57, v59\n\t"
 
-#define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
-	"1:\n\t"                                                                                                           \
+#ifndef CSNAPPY_HOPS_UNROLL
+#define CSNAPPY_HOPS_UNROLL 1
+#endif
+#define CSNAPPY_ISA_HOP(BR) \
 	"s_bitset1_b64 s[68:69], s80\n\t"                                                                                  \
 	"v_readlane_b32 s80, v35, s80\n\t"                                                                                 \
 	"s_nop 0\n\t"                                                                                                      \
 	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
-	"s_cbranch_scc1 1b\n\t"
+	BR
+#if CSNAPPY_HOPS_UNROLL
+/* (four hops a round: the branch of a hop that goes on falls through) */
+#define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
+	"1:\n\t"                                                                                                           \
+	CSNAPPY_ISA_HOP("s_cbranch_scc0 2f\n\t")                                                                           \
+	CSNAPPY_ISA_HOP("s_cbranch_scc0 2f\n\t")                                                                           \
+	CSNAPPY_ISA_HOP("s_cbranch_scc0 2f\n\t")                                                                           \
+	CSNAPPY_ISA_HOP("s_cbranch_scc1 1b\n\t")                                                                           \
+	"2:\n\t"
+#else
+#define CSNAPPY_ISA_HOPS /* t = nx[t] until t >= 64, every lane passed marked in `taken` */                            \
+	"1:\n\t"                                                                                                           \
+	CSNAPPY_ISA_HOP("s_cbranch_scc1 1b\n\t")
+#endif
 
 #define CSNAPPY_ISA_PREFIX16(d, a, b, c) /* d = equal leading bytes (0..16) of the strings whose XOR is d, a, b, c */  \
 	"v_ffbl_b32_e32 " d ", " d "\n\t"                                                                                  \
@@ -668,7 +721,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
  * another round, the next step's loads and the commit (behind label 11) */
 #define CSNAPPY_ISA_TABLE_DENSE \
 	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
-	"s_waitcnt vmcnt(0)\n\t"                           /* own bytes and id */                                          \
+	CSNAPPY_ISA_DENSE_OWN_WAIT                         /* own bytes and id */                                          \
 	"v_lshlrev_b32_e32 v36, 1, v42\n\t"                /* my table entry (id 0: the dummy) */                          \
 	"ds_read_u16 v56, v36\n\t"                                                                                         \
 	"v_and_b32_e32 v37, 0xfffc, v36\n\t"               /* its dword */                                                 \
@@ -687,26 +740,119 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_and_b64 s[70:71], vcc, s[60:61]\n\t"            /* the candidate can match at all */                            \
 	"v_cndmask_b32_e64 v59, 0, v34, s[70:71]\n\t"                                                                      \
 	"global_load_dwordx4 v[52:55], v59, %[src]\n\t"    /* candidate gather (no candidate: position 0) */               \
-	"global_store_dwordx2 v43, v[50:51], %[R]\n\t"     /* the previous step's records, behind the gather */            \
+	"global_store_dwordx2 v43, v[50:51], %[R]" CSNAPPY_NT_REC "\n\t" /* the previous step's records, behind the gather */ \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	CSNAPPY_ISA_P("v66")                                                                                               \
 	"v_bfe_u32 v57, v57, v58, 16\n\t"                  /* my half as the add found it */                               \
 	"v_cmp_ne_u32_e32 vcc, v57, v56\n\t"               /* not the entry: a lower lane has my slot */                   \
 	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes */                                             \
-	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */
+	"s_waitcnt vmcnt(1)\n\t"                           /* the gather (the store may be on its way) */                  \
+	CSNAPPY_ISA_P("v67")
 
 #define CSNAPPY_ISA_GO_DENSE \
 	"s_cmp_lt_u32 %[p0], %[limit64]\n\t"                                                                               \
 	"s_cselect_b32 s82, %[q1], 99\n\t"                 /* next step in this loop too: < 33 */
 
+#if CSNAPPY_TIMING_TA == 3 /* timing experiment: what one more dependent round trip in front of the step's loads costs */
+#define CSNAPPY_TIMING_ROUND_TRIP "v_lshlrev_b32_e32 v48, 1, v49\n\tglobal_load_ushort v56, v48, %[ids]\n\ts_waitcnt vmcnt(0)\n\t"
+#else
+#define CSNAPPY_TIMING_ROUND_TRIP ""
+#endif
+#if CSNAPPY_DENSE_WINDOW
+/* The dense loop's own bytes and ids (round 6, second half).  Until here the next step's 16 bytes per lane and its id
+ * were requested when the cursor was known and waited for at the top of the step: a memory round trip on the step's
+ * chain, in front of the table read and the candidate gather (a dependent load more in that place costs 20 % of the
+ * parser's time: CSNAPPY_TIMING_TA=3).  Now every step requests a WINDOW anchored at its own cursor a -- lane l the
+ * aligned dword 4l of the input from a & ~3 (256 bytes) and the dword of ids 2l, 2l + 1 from a & ~1 (128 positions) --
+ * which nobody needs before the NEXT cursor is known, a whole step later: the next step starts d <= 63 positions
+ * further (its last copy ended inside the step or one behind it), its 79 bytes and 64 ids lie inside the window, and
+ * every lane picks them out of the others' registers (ds_bpermute: the LDS crossbar, ~a tenth of the round trip,
+ * under the records' DPP chain).  d > 63 (a copy ran on past the step: one step in seven on text): the window just
+ * requested for the new cursor is waited for, as before.
+ *   v60 / v61  the window being loaded (bytes / ids), anchor s92     v62 / v63  the one in use
+ *   s93 / s94  the highest dword the windows may touch (bytes / ids)
+ *   v52, v54-v57, v49 the permutes' results, v35 / v33 the byte shift / the id's half: untouched up to label 15 */
+#define CSNAPPY_ISA_WINDOW_REQUEST(P) /* the windows anchored at cursor P -> v60, v61; s92 = P */                         \
+	"s_and_b32 s84, " P ", -4\n\t"                                                                                     \
+	"s_and_b32 s85, " P ", -2\n\t"                                                                                     \
+	"v_lshl_add_u32 v48, %[lane], 2, s84\n\t"                                                                          \
+	"s_lshl_b32 s85, s85, 1\n\t"                                                                                       \
+	"v_min_u32_e32 v48, s93, v48\n\t"                  /* (clamped: a window may reach past the fragment's end) */     \
+	"s_mov_b32 s92, " P "\n\t"                                                                                         \
+	"global_load_dword v60, v48, %[src]\n\t"                                                                           \
+	"v_lshl_add_u32 v48, %[lane], 2, s85\n\t"                                                                          \
+	"v_min_u32_e32 v48, s94, v48\n\t"                                                                                  \
+	"global_load_dword v61, v48, %[ids]" CSNAPPY_NT_IDL "\n\t"
+
+#define CSNAPPY_ISA_ENTRY_DENSE \
+	"s_sub_u32 s93, %[n], 4\n\t"                                                                                       \
+	"s_sub_u32 s94, %[n], 2\n\t"                                                                                       \
+	"s_and_b32 s93, s93, -4\n\t"                       /* the last whole dword of the input */                         \
+	"s_and_b32 s94, s94, -2\n\t"                                                                                       \
+	"s_lshl_b32 s94, s94, 1\n\t"                       /* ... and of the ids, as a byte offset */                      \
+	CSNAPPY_ISA_WINDOW_REQUEST("%[p0]")
+
+#define CSNAPPY_ISA_LOADS_DENSE \
+	"s_sub_u32 s88, %[p0], s92\n\t"                    /* d: how far the cursor moved */                               \
+	"s_and_b32 s87, s92, 3\n\t"                                                                                        \
+	"s_and_b32 s86, s92, 1\n\t"                                                                                        \
+	"s_cmp_gt_u32 s88, 63\n\t"                                                                                         \
+	"s_cbranch_scc0 2f\n\t"                                                                                            \
+	CSNAPPY_ISA_WINDOW_REQUEST("%[p0]")                /* beyond the old window: the new one, now */                   \
+	"s_and_b32 s87, %[p0], 3\n\t"                                                                                      \
+	"s_and_b32 s86, %[p0], 1\n\t"                                                                                      \
+	"s_mov_b32 s88, 0\n\t"                                                                                             \
+	"s_waitcnt vmcnt(0)\n\t"                                                                                           \
+	"2:\n\t"                                                                                                           \
+	"s_add_u32 s87, s87, s88\n\t"                      /* the cursor's byte in the window of bytes */                  \
+	"s_add_u32 s86, s86, s88\n\t"                      /* ... its id in the window of ids */                           \
+	"v_add_u32_e32 v35, s87, %[lane]\n\t"              /* where my 16 bytes begin in the window */                     \
+	"v_add_u32_e32 v33, s86, %[lane]\n\t"              /* ... and my id */                                             \
+	"s_waitcnt vmcnt(1)\n\t"                           /* the window requested a step ago (the records' store, issued  \
+	                                                     * behind it, may be on its way) */                            \
+	"v_mov_b32_e32 v62, v60\n\t"                                                                                       \
+	"v_mov_b32_e32 v63, v61\n\t"                                                                                       \
+	"v_and_b32_e32 v34, -4, v35\n\t"                                                                                   \
+	"v_lshlrev_b32_e32 v49, 1, v33\n\t"                                                                                \
+	"ds_bpermute_b32 v52, v34, v62\n\t"                                                                                \
+	"v_and_b32_e32 v49, -4, v49\n\t"                   /* the lane that holds the dword of ids mine is in */           \
+	"ds_bpermute_b32 v54, v34, v62 offset:4\n\t"                                                                       \
+	"ds_bpermute_b32 v49, v49, v63\n\t"                                                                                \
+	"ds_bpermute_b32 v55, v34, v62 offset:8\n\t"                                                                       \
+	"ds_bpermute_b32 v56, v34, v62 offset:12\n\t"                                                                      \
+	"ds_bpermute_b32 v57, v34, v62 offset:16\n\t"                                                                      \
+	"v_lshlrev_b32_e32 v33, 4, v33\n\t"                /* bits 4:0: 16 * (my id is the dword's high half) */           \
+	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
+	"s_cmp_eq_u32 s92, %[p0]\n\t"                      /* (requested above) */                                         \
+	"s_cbranch_scc1 3f\n\t"                                                                                            \
+	CSNAPPY_ISA_WINDOW_REQUEST("%[p0]")                /* the window of the step behind the next */                    \
+	"3:\n\t"
+
+#define CSNAPPY_ISA_DENSE_OWN_WAIT ""
+#define CSNAPPY_ISA_DENSE_OWN_FINISH /* label 15, in front of the commit: the permutes are back */                      \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_alignbyte_b32 v44, v54, v52, v35\n\t"           /* my own 16 bytes */                                           \
+	"v_alignbyte_b32 v45, v55, v54, v35\n\t"                                                                           \
+	"v_alignbyte_b32 v46, v56, v55, v35\n\t"                                                                           \
+	"v_alignbyte_b32 v47, v57, v56, v35\n\t"                                                                           \
+	"v_bfe_u32 v42, v49, v33, 16\n\t"                  /* my id */
+
+#else
+#define CSNAPPY_ISA_ENTRY_DENSE ""
+#define CSNAPPY_ISA_DENSE_OWN_WAIT "s_waitcnt vmcnt(0)\n\t"
+#define CSNAPPY_ISA_DENSE_OWN_FINISH ""
 #define CSNAPPY_ISA_LOADS_DENSE \
 	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
 	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
+	CSNAPPY_TIMING_ROUND_TRIP                                                                      \
 	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"                                                                    \
 	CSNAPPY_TIMING_EXTRA_LOAD                                                                      \
 	"v_lshlrev_b32_e32 v48, 1, v49\n\t"                                                                                \
-	"global_load_ushort v42, v48, %[ids]\n\t"
+	"global_load_ushort v42, v48, %[ids]" CSNAPPY_NT_IDL "\n\t"
 
-#define CSNAPPY_ISA_COMMIT_DENSE \
+#endif
+#define CSNAPPY_ISA_COMMIT_DENSE CSNAPPY_ISA_DENSE_OWN_FINISH CSNAPPY_ISA_COMMIT_LDS
+#define CSNAPPY_ISA_COMMIT_LDS \
 	"v_cmp_ge_u32_e32 vcc, s72, %[lane]\n\t"           /* lanes up to e_final */                                       \
 	"ds_sub_u32 v37, v38\n\t"                          /* the adds are taken back */                                   \
 	"s_andn2_b64 s[70:71], vcc, s[70:71]\n\t"          /* inserted lanes */                                            \
@@ -952,9 +1098,11 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_mov_b32_e32 v41, 32\n\t"                                                                                        \
 	"s_mov_b32 s83, m0\n\t"                            /* (m0 is the compiler's: given back at 19) */                  \
 	ENTRY                                                                                                              \
+	CSNAPPY_ISA_P0                                                                                                     \
 	"s_branch 12f\n\t"                                                                                                 \
 	/* ================= BACK: the walk has left the step and took at least one copy ================= */            \
 	"10:\n\t"                                                                                                          \
+	CSNAPPY_ISA_P("v69")                                                                                               \
 	"s_flbit_i32_b64 s72, s[68:69]\n\t"                                                                                \
 	"s_xor_b32 s72, s72, 63\n\t"                       /* the last copy's lane */                                      \
 	"v_mov_b32_e32 v58, %[nemit]\n\t"                  /* where the pending literal starts */                          \
@@ -999,11 +1147,14 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_cmp_lt_u32_e64 s[70:71], v53, v58\n\t"          /* strictly inside a copy: never inserted */                    \
 	/* ---- 15: this step's commit ---- */                                                                             \
 	"15:\n\t"                                                                                                          \
+	CSNAPPY_ISA_P("v70")                                                                                               \
 	COMMIT                                                                                                             \
 	"s_cmp_lt_u32 s82, 33\n\t"                                                                                         \
 	"s_cbranch_scc0 19f\n\t"                                                                                           \
 	/* ================= FRONT ================= */                                                                  \
 	"12:\n\t"                                                                                                          \
+	CSNAPPY_ISA_P("v65")                                                                                               \
+	CSNAPPY_ISA_PSTEP                                                                                                  \
 	TABLE                                                                                                              \
 	"v_xor_b32_e32 v52, v52, v44\n\t"                                                                                  \
 	"v_xor_b32_e32 v53, v53, v45\n\t"                                                                                  \
@@ -1030,6 +1181,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"v_lshl_or_b32 v56, v52, 7, v55\n\t"               /* lane | 128: a special one */                                 \
 	"v_cndmask_b32_e32 v35, 64, v56, vcc\n\t"          /* next stop of the chain if my match is taken (64: none here) */ \
 	"s_mov_b64 s[68:69], 0\n\t"                                                                                        \
+	CSNAPPY_ISA_P("v68")                                                                                               \
 	"v_readlane_b32 s80, v35, 0\n\t"                   /* the walk: lane 0 holds the first stop */                     \
 	"s_nop 0\n\t"                                                                                                      \
 	"s_cmp_lt_u32 s80, 64\n\t"                                                                                         \
@@ -1224,6 +1376,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	"s_cbranch_scc1 10b\n\t"                                                                                           \
 	/* no copy in the whole step: the scan goes on behind its last probe (csnappy_compress.c:535-552);       \
 	 * nothing to record; every lane up to that probe is inserted */                                                \
+	CSNAPPY_ISA_P("v69")                                                                                               \
 	"s_min_u32 s72, s81, 63\n\t"                       /* e_final */                                                   \
 	"v_mov_b32_e32 v50, 0\n\t"                                                                                         \
 	"v_mov_b32_e32 v51, 0\n\t"                                                                                         \
@@ -1235,6 +1388,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 	LOADS                                                                                                              \
 	"s_branch 15b\n\t"                                                                                                 \
 	"19:\n\t"                                                                                                          \
+	"s_waitcnt vmcnt(0)\n\t"                           /* (loads into registers that are the block's own) */           \
 	"s_mov_b32 m0, s83\n\t"
 
 template <int TAB, bool SPILL, bool PROF = false, bool ORD = true>
@@ -1538,19 +1692,42 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				register uint32_t px asm("v50") = prec.x, py asm("v51") = prec.y, poff asm("v43") = prec_off;
 				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
 				uint32_t nemit = next_emit;
-				asm volatile(CSNAPPY_ISA_LOOP("", CSNAPPY_ISA_TABLE_DENSE, CSNAPPY_ISA_GO_DENSE, CSNAPPY_ISA_LOADS_DENSE,
-							      CSNAPPY_ISA_COMMIT_DENSE)
+#if CSNAPPY_ISA_PROF
+				register uint32_t a65 asm("v65") = 0, a66 asm("v66") = 0, a67 asm("v67") = 0, a68 asm("v68") = 0;
+				register uint32_t a69 asm("v69") = 0, a70 asm("v70") = 0, a71 asm("v71") = 0;
+#define CSNAPPY_ISA_PROF_OUT , "+v"(a65), "+v"(a66), "+v"(a67), "+v"(a68), "+v"(a69), "+v"(a70), "+v"(a71)
+#define CSNAPPY_ISA_PROF_CLOBBER "s96", "s97", "s98", "s99",
+#else
+#define CSNAPPY_ISA_PROF_OUT
+#define CSNAPPY_ISA_PROF_CLOBBER
+#endif
+				asm volatile(CSNAPPY_ISA_LOOP(CSNAPPY_ISA_ENTRY_DENSE, CSNAPPY_ISA_TABLE_DENSE, CSNAPPY_ISA_GO_DENSE,
+							      CSNAPPY_ISA_LOADS_DENSE, CSNAPPY_ISA_COMMIT_DENSE)
 					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0),
 					       "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
+					       CSNAPPY_ISA_PROF_OUT
 					     : [src] "s"(src), [R] "s"(R), [ids] "s"(ids), [shm1] "s"(shift - 1), [mul] "s"(kHashMul),
 					       [limit64] "s"(limit64), [safemax] "s"(n - 16), [safemax4] "s"(n - 4), [n] "s"(n), [lane] "v"(lane),
 					       [thr] "v"(thr),
 					       [norec] "v"(no_rec_off)
 					     : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v41", "v48", "v49", "v52", "v53",
-					       "v54", "v55", "v56", "v57", "v58", "v59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+					       "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "s60", "s61",
+					       "s62", "s63", "s64", "s65", "s66",
 					       "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
-					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc",
-					       "scc", "memory");
+					       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+					       "s93", "s94", CSNAPPY_ISA_PROF_CLOBBER "vcc", "scc", "memory");
+#if CSNAPPY_ISA_PROF
+				if (lane == 0) {
+					atomicAdd(&g_isa_prof[0], (unsigned long long)a65);
+					atomicAdd(&g_isa_prof[1], (unsigned long long)a66);
+					atomicAdd(&g_isa_prof[2], (unsigned long long)a67);
+					atomicAdd(&g_isa_prof[3], (unsigned long long)a68);
+					atomicAdd(&g_isa_prof[4], (unsigned long long)a69);
+					atomicAdd(&g_isa_prof[5], (unsigned long long)a70);
+					atomicAdd(&g_isa_prof[6], 1ull);
+					atomicAdd(&g_isa_prof[7], (unsigned long long)a71);
+				}
+#endif
 				/* (the loads its last step requested are still on their way: clamped addresses, nobody
 				 * wants them) */
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(vsid));
@@ -1595,7 +1772,7 @@ DEVINL void parse_lean(const CompressArgs &A, const Frag &F)
 				const uint32_t thr = lane == 0 ? 0u : 0x8000u;
 				uint32_t nemit = next_emit;
 				asm volatile(CSNAPPY_ISA_LOOP("s_mov_b64 s[60:61], -1\n\t", CSNAPPY_ISA_TABLE_HASH, CSNAPPY_ISA_GO_DENSE,
-							      CSNAPPY_ISA_LOADS_HASH, CSNAPPY_ISA_COMMIT_DENSE)
+							      CSNAPPY_ISA_LOADS_HASH, CSNAPPY_ISA_COMMIT_LDS)
 					     : [p0] "+s"(pz), [q1] "+s"(q1), [nemit] "+s"(nemit), [nev] "+s"(nev), "+v"(x0), "+v"(x1),
 					       "+v"(x2), "+v"(x3), "+v"(vpos), "+v"(px), "+v"(py), "+v"(poff)
 					     : [src] "s"(src), [R] "s"(R), [shm1] "s"(shift - 1), [shift] "s"(shift), [mul] "s"(kHashMul),
@@ -2142,9 +2319,16 @@ DEVINL bool record_is_small(const RecFields &f, bool live, uint32_t avail)
 	return live && f.mine <= kBigRecord && (f.lit_len == 0 || f.lit_start + 32 <= avail);
 }
 
+/* The loads of fetch_record and fetch_literal are issued by every lane, whatever the chunk holds (a lane
+ * without a record or without a literal reads the fragment's first records instead): gfx9 counts loads in
+ * order in one counter, and only when the NUMBER of loads between a chunk's own and its first use is the
+ * same on every path can the wait in front of that use leave the next chunk's loads in flight.  With a
+ * branch around any of them the compiler has to wait for all of them -- vmcnt(0), once per chunk, a memory
+ * round trip that nothing covered (rounds 2 to 5). */
 DEVINL uint2 fetch_record(const uint2 *R, uint32_t first, uint32_t nev, uint32_t lane)
 {
-	return lane < nev ? R[first + lane] : make_uint2(0, 0);
+	const uint2 r = R[first + min(lane, nev - 1)]; /* (nev >= 1) */
+	return lane < nev ? r : make_uint2(0, 0);
 }
 
 /* the record whose literal travels in ChunkIn::mw: not small, a literal of 1..kMediumLiteral bytes */
@@ -2153,26 +2337,23 @@ DEVINL bool record_has_wide_literal(const RecFields &f, bool live, uint32_t avai
 	return live && !record_is_small(f, live, avail) && f.lit_len && f.lit_len <= kMediumLiteral;
 }
 
-DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t avail, uint32_t lane)
+DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t avail, uint32_t lane, const uint2 *R)
 {
 	const bool live = lane < nev;
 	const RecFields f = decode_record(c.r, live);
-	c.la = c.lb = make_uint4(0, 0, 0, 0);
-	c.mw = 0;
-	if (record_is_small(f, live, avail) && f.lit_len) {
-		__builtin_memcpy(&c.la, src + f.lit_start, 16);
-		__builtin_memcpy(&c.lb, src + f.lit_start + 16, 16);
-	}
+	/* (what a lane without a literal loads is never looked at: see `left` and the medium loop of emit_chunk) */
+	const uint8_t *scrap = reinterpret_cast<const uint8_t *>(R);
+	const uint8_t *pl = record_is_small(f, live, avail) && f.lit_len ? src + f.lit_start : scrap;
+	__builtin_memcpy(&c.la, pl, 16);
+	__builtin_memcpy(&c.lb, pl + 16, 16);
 	/* A literal of 32..256 bytes (text: one record in 150, one chunk in three) used to be fetched where it
-	 * is staged: a memory round trip in the middle of the chunk, a fifth of the kernel's time.  Its bytes are
-	 * one dword per lane: requested here, a chunk ahead, with the others'. */
+	 * is staged: a memory round trip in the middle of the chunk.  Its bytes are one dword per lane: requested
+	 * here, a chunk ahead, with the others'. */
 	const uint64_t wide = ballot64(record_has_wide_literal(f, live, avail));
-	if (wide) {
-		const uint32_t m = first_lane(wide);
-		const uint32_t ls = rdlane(f.lit_start, m), ll = rdlane(f.lit_len, m);
-		if (4 * lane < ll && ls + 4 * lane + 4 <= avail)
-			__builtin_memcpy(&c.mw, src + ls + 4 * lane, 4);
-	}
+	const uint32_t m = wide ? first_lane(wide) : 0u;
+	const uint32_t ls = rdlane(f.lit_start, m), ll = wide ? rdlane(f.lit_len, m) : 0u;
+	const uint8_t *pw = 4 * lane < ll && ls + 4 * lane + 4 <= avail ? src + ls + 4 * lane : scrap;
+	__builtin_memcpy(&c.mw, pw, 4);
 }
 
 /* `ahead` = the loads already issued for the wave's next chunk: they are waited for in front of
@@ -2204,7 +2385,8 @@ struct EmitState {
 	uint32_t fill; /* staged bytes */
 };
 
-DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, const uint8_t *src, uint32_t avail,
+template <class Prefetch>
+DEVINL uint32_t emit_chunk(const ChunkIn &in, Prefetch &&prefetch, uint32_t nev, const uint8_t *src, uint32_t avail,
 			   uint8_t *dst, uint8_t *stage, uint32_t lane, EmitState &st, bool last_chunk EMIT_PROF_ARG)
 {
 #if CSNAPPY_EMIT_PROF
@@ -2218,8 +2400,10 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 
 	auto drain = [&]() {
 		wave_lds_fence();
-		asm volatile("" : "+v"(ahead.r.x), "+v"(ahead.r.y), "+v"(ahead.la.x), "+v"(ahead.la.y), "+v"(ahead.la.z),
-			     "+v"(ahead.la.w), "+v"(ahead.lb.x), "+v"(ahead.lb.y), "+v"(ahead.lb.z), "+v"(ahead.lb.w), "+v"(ahead.mw));
+		/* (loads before stores: gfx9 has one counter for both, and a wait behind the stores would also sit out
+		 * their round trip.  The wait itself, not a use of the loaded registers that makes the compiler wait: those
+		 * would become values of the loop around the drain, copied at its head behind a wait for all of them) */
+		asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 		uint8_t *gbase = dst + gpos - sa; /* 16 B aligned */
 		const uint32_t end = sa + fill;
 		uint32_t first_full = 0;
@@ -2264,6 +2448,11 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, ChunkIn &ahead, uint32_t nev, cons
 	EMIT_TICK(0); /* decode, offsets (and the wait for the chunk's own loads) */
 	if (fill && fill + total > kStageCap)
 		drain(); /* (a chunk with a big record may exceed the staging by itself: its runs do not) */
+	/* The next chunk's loads go out HERE: behind this chunk's own (a chunk old, waited for at its top) and behind the
+	 * drain's stores, so that nothing in this chunk waits for memory -- the next chunk's top does, a chunk later,
+	 * when loads and stores are long back.  (Issued in front of the drain they were what its stores waited for,
+	 * a round trip every third chunk; issued before this chunk's top they made its wait theirs.) */
+	prefetch();
 	while (nev) {
 		const uint32_t seg_hi = bigmask ? first_lane(bigmask) : nev; /* one past the run */
 		if (seg_hi > seg_lo) {
@@ -2520,25 +2709,32 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_pag
 	const uint2 *R = reinterpret_cast<const uint2 *>(A.recs + (uint64_t)b * A.rec_cap);
 	const uint8_t *src = A.in + A.in_off[blk];
 	/* records are fetched two chunks ahead, literal bytes one chunk ahead */
+	if (cnt == 0) {
+		if (lane == 0)
+			A.out_len[blk] = pos;
+		return;
+	}
+	/* (the loads behind the last chunk are those of the last chunk again: every iteration issues the same number) */
+	const uint32_t r_last = (cnt - 1) & ~63u;
 	ChunkIn cur, nxt;
 	nxt.r = fetch_record(R, 0, min(64u, cnt), lane);
-	uint2 r2 = cnt > 64 ? fetch_record(R, 64, min(64u, cnt - 64), lane) : make_uint2(0, 0);
-	if (cnt)
-		fetch_literal(nxt, min(64u, cnt), src, len, lane);
+	uint2 r2 = fetch_record(R, min(64u, r_last), min(64u, cnt - min(64u, r_last)), lane);
+	fetch_literal(nxt, min(64u, cnt), src, len, lane, R);
 	EmitState st = { 0, 0 };
 	uint8_t *body = dst + pos;
 	for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
 		cur = nxt;
 		nxt.r = r2;
-		if (r0 + 128 < cnt)
-			r2 = fetch_record(R, r0 + 128, min(64u, cnt - r0 - 128), lane);
-		if (r0 + 64 < cnt)
-			fetch_literal(nxt, min(64u, cnt - r0 - 64), src, len, lane);
+		const uint32_t r1 = min(r0 + 64, r_last), r2at = min(r0 + 128, r_last);
+		auto prefetch = [&]() __attribute__((always_inline)) {
+			r2 = fetch_record(R, r2at, min(64u, cnt - r2at), lane);
+			fetch_literal(nxt, min(64u, cnt - r1), src, len, lane, R);
+		};
 #if CSNAPPY_EMIT_PROF
 		unsigned long long ept_pages[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt, ept_pages);
+		pos += emit_chunk(cur, prefetch, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt, ept_pages);
 #else
-		pos += emit_chunk(cur, nxt, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt);
+		pos += emit_chunk(cur, prefetch, min(64u, cnt - r0), src, len, body, stage_all[wv], lane, st, r0 + 64 >= cnt);
 #endif
 	}
 	if (lane == 0)
@@ -2695,7 +2891,10 @@ extern "C" __global__ void __launch_bounds__(64) snappy_emit_bases(CompressArgs 
 		A.out_len[blk] = pos;
 }
 
-extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blocks(CompressArgs A)
+#ifndef CSNAPPY_EMIT_OCC
+#define CSNAPPY_EMIT_OCC 4 /* waves per SIMD the register allocation aims at */
+#endif
+extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, CSNAPPY_EMIT_OCC) snappy_emit_blocks(CompressArgs A)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t stage_all[kEmitWaves][kStageBytes];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2716,28 +2915,29 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, 4) snappy_emit_blo
 #endif
 	const uint32_t per = (nchunks + kEmitWaves - 1) / kEmitWaves;
 	const uint32_t c_lo = min(wv * per, nchunks), c_hi = min(c_lo + per, nchunks);
+	if (c_lo >= c_hi)
+		return;
 	ChunkIn cur, nxt;
 	auto cn = [&](uint32_t ch) { return min(64u, cnt - ch * 64); };
-	uint2 r2 = make_uint2(0, 0);
-	if (c_lo < c_hi) {
-		nxt.r = fetch_record(R, c_lo * 64, cn(c_lo), lane);
-		if (c_lo + 1 < c_hi)
-			r2 = fetch_record(R, (c_lo + 1) * 64, cn(c_lo + 1), lane);
-		fetch_literal(nxt, cn(c_lo), src, avail, lane);
-	}
+	/* (the loads behind the wave's last chunk are those of its last chunk again: every iteration issues the same number) */
+	const uint32_t c_last = c_hi - 1;
+	nxt.r = fetch_record(R, c_lo * 64, cn(c_lo), lane);
+	uint2 r2 = fetch_record(R, min(c_lo + 1, c_last) * 64, cn(min(c_lo + 1, c_last)), lane);
+	fetch_literal(nxt, cn(c_lo), src, avail, lane, R);
 	EmitState st = { 0, 0 };
-	uint8_t *body = dst + (c_lo < c_hi ? F.base[c_lo] : 0u);
+	uint8_t *body = dst + F.base[c_lo];
 	for (uint32_t ch = c_lo; ch < c_hi; ++ch) {
 		cur = nxt;
 		nxt.r = r2;
-		if (ch + 2 < c_hi)
-			r2 = fetch_record(R, (ch + 2) * 64, cn(ch + 2), lane);
-		if (ch + 1 < c_hi)
-			fetch_literal(nxt, cn(ch + 1), src, avail, lane);
+		const uint32_t c1 = min(ch + 1, c_last), c2 = min(ch + 2, c_last);
+		auto prefetch = [&]() __attribute__((always_inline)) {
+			r2 = fetch_record(R, c2 * 64, cn(c2), lane);
+			fetch_literal(nxt, cn(c1), src, avail, lane, R);
+		};
 #if CSNAPPY_EMIT_PROF
-		(void)emit_chunk(cur, nxt, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi, ept);
+		(void)emit_chunk(cur, prefetch, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi, ept);
 #else
-		(void)emit_chunk(cur, nxt, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi);
+		(void)emit_chunk(cur, prefetch, cn(ch), src, avail, body, stage_all[wv], lane, st, ch + 1 == c_hi);
 #endif
 	}
 #if CSNAPPY_EMIT_PROF
@@ -4457,6 +4657,17 @@ int csnappy_hip_debug_emit_prof(unsigned long long *out16)
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_emit_prof), sizeof(zero)) != hipSuccess)
 		return -1;
 	return hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#if CSNAPPY_ISA_PROF
+/* development builds only: read (and clear) the dense step loop's phase counters */
+extern "C" int csnappy_hip_debug_isa_prof(unsigned long long *out16)
+{
+	static const unsigned long long zero[16] = { 0 };
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_isa_prof), sizeof(zero)) != hipSuccess)
+		return -1;
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_isa_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
 
