@@ -397,6 +397,9 @@ DEVINL bool frag_setup(const CompressArgs &A, Frag &F, bool gtab)
  * in use -- buckets + kFirstBucket, the table entries the fragment needs --, or kNoRecords when the
  * fragment was handed to a later launch (too many buckets, or repetitive: the global-table launch is
  * faster for it). */
+#ifndef CSNAPPY_PROLOGUE_PAIRS
+#define CSNAPPY_PROLOGUE_PAIRS 1 /* 0: the bitmap and its prefix as two arrays (A/B) */
+#endif
 DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -521,6 +524,30 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 			A.rec_cnt[F.c] = kNoRecords;
 		return kNoRecords;
 	}
+#if CSNAPPY_PROLOGUE_PAIRS
+	/* (round 6) the second sweep reads a word of the bitmap and its prefix for every position: the two as ONE
+	 * 8-byte entry, built over the two bitmaps (the first is done with; every lane holds its words of the second in
+	 * registers before the first pair is written): half the sweep's LDS reads */
+	uint2 *pairs = reinterpret_cast<uint2 *>(smem);
+	{
+		uint32_t s2w[16]; /* per <= 16: nwords <= 1024 */
+#pragma unroll
+		for (uint32_t k = 0; k < 16; ++k) {
+			const uint32_t w = lane * per + k;
+			s2w[k] = (k < per && w < nwords) ? seen2[w] : 0u;
+		}
+		wave_lds_fence();
+#pragma unroll
+		for (uint32_t k = 0; k < 16; ++k) {
+			const uint32_t w = lane * per + k;
+			if (k < per && w < nwords) {
+				pairs[w] = make_uint2(s2w[k], run);
+				run += (uint32_t)__builtin_popcount(s2w[k]);
+			}
+		}
+	}
+	(void)pref;
+#else
 	for (uint32_t k = 0; k < per; ++k) {
 		const uint32_t w = lane * per + k;
 		if (w < nwords) {
@@ -528,6 +555,7 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 			run += (uint32_t)__builtin_popcount(seen2[w]);
 		}
 	}
+#endif
 	wave_lds_fence();
 	uint16_t *wids = reinterpret_cast<uint16_t *>(F.region);
 	sweep([&](const uint4 &v, uint32_t i, uint32_t cntp) {
@@ -535,7 +563,12 @@ DEVINL uint32_t dense_prologue(const CompressArgs &A, const Frag &F)
 		hash8(v, hh);
 #pragma unroll
 		for (uint32_t k = 0; k < 8; ++k) {
+#if CSNAPPY_PROLOGUE_PAIRS
+			const uint2 pr = pairs[hh[k] >> 5];
+			const uint32_t s2 = pr.x, pf = pr.y;
+#else
 			const uint32_t s2 = seen2[hh[k] >> 5], pf = pref[hh[k] >> 5];
+#endif
 			const uint32_t b = 1u << (hh[k] & 31);
 			id[k] = (k < cntp && (s2 & b)) ? pf + (uint32_t)__builtin_popcount(s2 & (b - 1)) : kNoBucket;
 		}
@@ -2283,6 +2316,9 @@ extern "C" __global__ void __launch_bounds__(64, 5) snappy_parse_fragments_gtab_
  * every wave encodes its 64-record chunks into its own LDS staging and flushes them with aligned
  * 16 B/lane stores at the chunk's final place in the block's slot -- nothing is moved twice.
  * ======================================================================================== */
+#ifndef CSNAPPY_EMIT_DECODE_ONCE
+#define CSNAPPY_EMIT_DECODE_ONCE 1 /* 0: emit_chunk decodes its records again (A/B: +3 % emit time) */
+#endif
 struct RecFields {
 	uint32_t lit_start, lit_len, coff, clen, lhdr, mine;
 	CopyPlan cp;
@@ -2309,6 +2345,9 @@ struct ChunkIn {
 	uint4 la, lb; /* 32 bytes at the record's literal (small records only) */
 	uint32_t mw; /* dword `lane` of the literal of the chunk's first record with a literal of up to kMediumLiteral bytes
 		      * that is not small (round 6: fetched with the chunk, not when its turn comes) */
+#if CSNAPPY_EMIT_DECODE_ONCE
+	RecFields f; /* the record decoded (fetch_literal needs it for the literal's address: emit_chunk takes it from here) */
+#endif
 };
 
 DEVINL bool record_is_small(const RecFields &f, bool live, uint32_t avail)
@@ -2341,6 +2380,9 @@ DEVINL void fetch_literal(ChunkIn &c, uint32_t nev, const uint8_t *src, uint32_t
 {
 	const bool live = lane < nev;
 	const RecFields f = decode_record(c.r, live);
+#if CSNAPPY_EMIT_DECODE_ONCE
+	c.f = f;
+#endif
 	/* (what a lane without a literal loads is never looked at: see `left` and the medium loop of emit_chunk) */
 	const uint8_t *scrap = reinterpret_cast<const uint8_t *>(R);
 	const uint8_t *pl = record_is_small(f, live, avail) && f.lit_len ? src + f.lit_start : scrap;
@@ -2427,7 +2469,11 @@ DEVINL uint32_t emit_chunk(const ChunkIn &in, Prefetch &&prefetch, uint32_t nev,
 	};
 
 	const bool live = lane < nev;
+#if CSNAPPY_EMIT_DECODE_ONCE
+	const RecFields f = in.f;
+#else
 	const RecFields f = decode_record(in.r, live);
+#endif
 	const uint32_t lit_start = f.lit_start, lit_len = f.lit_len, coff = f.coff, clen = f.clen;
 	const uint32_t lhdr = f.lhdr, mine = f.mine;
 	const CopyPlan cp = f.cp;
@@ -4929,7 +4975,14 @@ int csnappy_hip_decompress_batch(const void *d_in, const uint64_t *d_in_off,
 	A.skip_if = nullptr;
 	Timer t(st);
 	t.start();
-	hipLaunchKernelGGL(snappy_decompress_blocks, dim3(nblocks), dim3(64), 0, st, A);
+	/* (experiments: CSNAPPY_HIP_DEC_WGS_PER_CU caps the blocks in flight per CU by padding the LDS request) */
+	static const uint32_t dec_pad = [] {
+		const char *e = getenv("CSNAPPY_HIP_DEC_WGS_PER_CU");
+		const unsigned long v = e && *e ? strtoul(e, nullptr, 10) : 0;
+		return v >= 1 && v <= 32 ? (uint32_t)((kLdsPerCu / v) & ~255u) : 0u;
+	}();
+	const uint32_t dec_static = 512 + 2048 + kOutStage + 16 + 64;
+	hipLaunchKernelGGL(snappy_decompress_blocks, dim3(nblocks), dim3(64), dec_pad > dec_static ? dec_pad - dec_static : 0, st, A);
 	t.stop(2);
 	if (!hip_ok(hipGetLastError(), "launch snappy_decompress_blocks"))
 		return CSNAPPY_HIP_E_RUNTIME;
