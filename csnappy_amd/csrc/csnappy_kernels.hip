@@ -4507,7 +4507,7 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 	 * (its prologue costs ~8 %): 64 KiB blocks at p <= 13 -> hash, 4 KiB pages at p = 13 -> dense
 	 * (2 112 entries instead of 4 096: 30 instead of 16 pages per CU, +6 %) */
 	{
-		const uint32_t scratch0 = 10u * (slots >> 5);
+		const uint32_t scratch0 = (CSNAPPY_PROLOGUE_PAIRS ? 8u : 10u) * (slots >> 5);
 		const uint32_t dense_lds0 = 2 * cap > scratch0 ? 2 * cap : scratch0;
 		const bool hash_ok = (1u << p) <= kHashLdsMaxBytes && (1u << p) * 10 <= dense_lds0 * 13;
 		P.tab = kn.table >= 0 ? kn.table : (hash_ok ? TAB_LDS_HASH : TAB_LDS_DENSE);
@@ -4529,7 +4529,7 @@ ParsePlan plan_parse(int p, uint32_t maxfrag, const Knobs &kn)
 		P.dense_cap = cap;
 		/* prologue: two bitmaps + the prefix.  The filters behind the table are set up after the
 		 * prologue, so they may lie inside its scratch. */
-		const uint32_t scratch = 10u * (slots >> 5);
+		const uint32_t scratch = (CSNAPPY_PROLOGUE_PAIRS ? 8u : 10u) * (slots >> 5);
 		dense_scratch = scratch;
 		P.lds0 = (2 * cap + 15) & ~15u;
 		P.fallback = cap < max_ids(maxfrag) || (kn.sample_min && maxfrag == kFragment);
