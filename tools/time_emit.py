@@ -3,7 +3,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 from csnappy_amd import api
 nb = 16384
-d_in = api.generate(0, 0xC5A90001, 0, nb, 65536)
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+d_in = api.generate(cfg, 0xC5A90001, 0, nb, 65536)
 b = api.Batch([65536] * nb)
 d_out = torch.zeros(b.out_bytes, dtype=torch.uint8, device="cuda")
 L = api.lib()
