@@ -2972,6 +2972,8 @@ extern "C" __global__ void __launch_bounds__(64 * kEmitWaves, CSNAPPY_EMIT_OCC) 
 	fetch_literal(nxt, cn(c_lo), src, avail, lane, R);
 	EmitState st = { 0, 0 };
 	uint8_t *body = dst + F.base[c_lo];
+	/* (two chunks an iteration with the two register sets changing roles instead of being copied -- 21 moves a chunk --
+	 * was slower: 1.07 against 0.99 ms per GiB, twice the code) */
 	for (uint32_t ch = c_lo; ch < c_hi; ++ch) {
 		cur = nxt;
 		nxt.r = r2;

@@ -215,6 +215,37 @@ def test_incompressible_and_all_zero_extremes(torch, chk):
         assert (st == 0).all() and [bytes(o) for o in outs] == [x.tobytes() for x in xs]
 
 
+def test_literals_of_every_length_between_copies_and_at_the_end(torch, chk):
+    """The emit kernels' three literal paths -- up to 31 bytes (fetched with the record, two 16-byte loads), 32..256
+    (one dword per lane, fetched with the chunk: round 6) and longer (straight to HBM) -- at every length around their
+    borders, in the middle of a block, as its last record without a copy behind it, and with fewer than four bytes
+    of input behind the literal (the prefetch's whole dwords end inside the input or the slow path takes it)."""
+    rng = np.random.default_rng(20261003)
+    motif = rng.integers(0, 256, 24, dtype=np.uint8)
+    xs = []
+    for L in list(range(0, 70)) + list(range(120, 136)) + list(range(248, 268)) + [300, 511, 512, 513, 1000]:
+        for tail in (0, 1, 2, 3, 5):
+            # a copy's source, literals of L bytes between copies of the motif, a literal of L (+ tail) bytes last
+            parts = [motif]
+            for _ in range(5):
+                parts += [rng.integers(0, 256, L, dtype=np.uint8), motif[: int(rng.integers(8, 25))]]
+            parts += [rng.integers(0, 256, L + tail, dtype=np.uint8)]
+            xs.append(np.concatenate(parts))
+    host = np.concatenate(xs)
+    lens = [len(x) for x in xs]
+    for p, mode in ((16, api.STREAM), (13, api.FRAGMENT), (10, api.STREAM)):
+        blocks, _, _ = gpu_compress(torch, host, lens, p, mode)
+        want = oracle_blocks(chk, host, lens, p, mode)
+        for i, (a, b) in enumerate(zip(blocks, want)):
+            assert a == b, f"p={p} block {i} (n={lens[i]}): {len(a)} vs {len(b)} bytes"
+        st, _, outs = gpu_decompress(torch, blocks, lens, mode)
+        assert (st == 0).all() and [bytes(o) for o in outs] == [x.tobytes() for x in xs]
+    # ... and many of them in ONE block: several medium literals in a chunk of 64 records, chunks of nothing else
+    big = np.concatenate(xs)[:65536]
+    blocks, _, _ = gpu_compress(torch, big, [len(big)], 16, api.STREAM)
+    assert blocks == oracle_blocks(chk, big, [len(big)], 16, api.STREAM)
+
+
 # -------------------------------------------------------------------------------------------------
 # decompress
 # -------------------------------------------------------------------------------------------------
