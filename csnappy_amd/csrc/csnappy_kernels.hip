@@ -1092,11 +1092,17 @@ __device__ unsigned long long g_isa_prof[16];
 	"s_cmp_lt_u32 s92, 2\n\t"                          /* ... unless the tags' epoch field runs out: the C++ step starts the array over */\
 	"s_cselect_b32 s82, 99, s82\n\t"
 
+#if CSNAPPY_TIMING_TA == 4 /* timing experiment: what one more dependent round trip in front of the global-table step's window costs */
+#define CSNAPPY_TIMING_ROUND_TRIP_G "global_load_dword v56, v49, %[src]\n\ts_waitcnt vmcnt(0)\n\t"
+#else
+#define CSNAPPY_TIMING_ROUND_TRIP_G ""
+#endif
 #define CSNAPPY_ISA_LOADS_GTAB \
 	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
 	"s_and_b32 s79, %[p0], -4\n\t"                     /* its window: aligned dwords from here, lane l takes dword l */\
 	"v_lshl_add_u32 v49, %[lane], 2, s79\n\t"                                                                          \
 	"v_min_u32_e32 v49, %[safemax4], v49\n\t"          /* (clamped: lanes >= 21 are not used, and the loads are harmless when the loop ends here) */\
+	CSNAPPY_TIMING_ROUND_TRIP_G                                                                                        \
 	"global_load_dword v44, v49, %[src]\n\t"
 
 #define CSNAPPY_ISA_COMMIT_GTAB \
