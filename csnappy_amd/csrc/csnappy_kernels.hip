@@ -4427,7 +4427,9 @@ uint32_t record_cap(uint32_t n)
  *                                                         the LDS serves one instruction's lanes (the ones a
  *                                                         device that fails snappy_lds_order_probe gets)
  *   CSNAPPY_HIP_NO_ISA     0..1                           1: no hand-written step loop: every step takes parse_lean's
- *                                                         compiled C++ (the loops' reference; same bytes, ~10 % slower) */
+ *                                                         compiled C++ (the loops' reference; same bytes, ~10 % slower)
+ * (and, read where it is used, once per process, not by the reload entry: CSNAPPY_HIP_DEC_WGS_PER_CU 1..32, a cap on the
+ * blocks the decompress kernel keeps in flight per CU -- tools/time_dec.py: 28 / 24 / 20 / 16 cost 14 / 26 / 36 / 44 %) */
 struct Knobs {
 	int table;      /* -1 auto, else TAB_* */
 	uint32_t dense_cap, s_entries, wgs_per_cu, sample_min, spill_cap;
