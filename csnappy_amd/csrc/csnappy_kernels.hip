@@ -280,7 +280,11 @@ DEVINL CopyPlan plan_copy(uint32_t len, uint32_t off)
 constexpr uint32_t kLocalMatch = 16;  /* lane-local match length cap */
 constexpr uint32_t kBigRecord = 32;   /* records encoding to more than this bypass the staging (but see kMediumLiteral) */
 constexpr uint32_t kMediumLiteral = 256; /* longest literal staged by the wave for its lane */
-constexpr uint32_t kStageCap = 64 * kBigRecord; /* bytes an emit wave stages before it drains: a chunk of small records fits (4 / 8 KiB: +-1 %, round 5) */
+#ifndef CSNAPPY_STAGE_CAP
+#define CSNAPPY_STAGE_CAP (64 * kBigRecord)
+#endif
+constexpr uint32_t kStageCap = CSNAPPY_STAGE_CAP; /* bytes an emit wave stages before it drains: a chunk of small records fits (4 / 8 KiB: +-1 %, round 5) */
+static_assert(kStageCap >= 64 * kBigRecord, "a chunk of small records fits the staging");
 constexpr uint32_t kStageBytes = 16 + kStageCap + 16 + 32; /* LDS output staging of one emit wave */
 constexpr uint32_t kNoRecords = 0xffffffffu;  /* rec_cnt: "not parsed yet: more buckets than this launch's dense table" */
 constexpr uint32_t kWantGlobal = 0xfffffffeu; /* rec_cnt: "not parsed yet: repetitive, take the global-table launch" */
