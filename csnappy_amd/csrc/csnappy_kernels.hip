@@ -756,6 +756,15 @@ __device__ unsigned long long g_isa_prof[16];
 
 /* the pieces that differ between the table placements: the FRONT's table access (label 12), the test for
  * another round, the next step's loads and the commit (behind label 11) */
+#if CSNAPPY_TIMING_TA == 5 /* timing experiment (wrong output where compiled steps mix in): no check bit, every lane with a bucket gathers */
+#define CSNAPPY_ISA_DENSE_CHECK_BIT "v_mov_b32_e32 v59, 0\n\t"
+#elif CSNAPPY_TIMING_TA == 6 /* ... the check bit kept, its multiply paid twice */
+#define CSNAPPY_ISA_DENSE_CHECK_BIT "v_mul_lo_u32 v59, v44, %[mul]\n\tv_mul_lo_u32 v59, v44, %[mul]\n\tv_bfe_u32 v59, v59, %[shm1], 1\n\t"
+#else
+#define CSNAPPY_ISA_DENSE_CHECK_BIT \
+	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
+	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */
+#endif
 #define CSNAPPY_ISA_TABLE_DENSE \
 	"s_sub_u32 s81, 33, %[q1]\n\t"                     /* probes the scan in progress has left */                      \
 	CSNAPPY_ISA_DENSE_OWN_WAIT                         /* own bytes and id */                                          \
@@ -766,8 +775,7 @@ __device__ unsigned long long g_isa_prof[16];
 	"v_lshlrev_b32_e64 v38, v58, 1\n\t"                /* 1 in my half */                                              \
 	"ds_add_rtn_u32 v57, v37, v38\n\t"                 /* comes back with the lower lanes' ones in it */               \
 	"v_writelane_b32 v41, s81, 0\n\t"                  /* lane 0 searches what is left of the scan, the others 33 probes */ \
-	"v_mul_lo_u32 v59, v44, %[mul]\n\t"                                                                                \
-	"v_bfe_u32 v59, v59, %[shm1], 1\n\t"               /* check bit: one more bit of my hash */                        \
+	CSNAPPY_ISA_DENSE_CHECK_BIT                                                                                        \
 	"v_cmp_ne_u32_e64 s[60:61], 0, v42\n\t"            /* lanes with a bucket */                                       \
 	"v_lshl_or_b32 v39, v59, 15, v40\n\t"              /* my entry, if I am inserted */                                \
 	"s_waitcnt lgkmcnt(1)\n\t"                         /* the entry (the add may be on its way) */                     \
