@@ -683,6 +683,18 @@ __device__ unsigned long long g_isa_prof[16];
 #define CSNAPPY_ISA_P(r) ""
 #define CSNAPPY_ISA_P0 ""
 #endif
+#if CSNAPPY_TIMING_TA == 8 /* timing experiment: one more 2-byte-per-lane load per step (the ids again) */
+#define CSNAPPY_TIMING_EXTRA_SMALL_LOAD "global_load_ushort v57, v48, %[ids]\n\t"
+#else
+#define CSNAPPY_TIMING_EXTRA_SMALL_LOAD ""
+#endif
+#if CSNAPPY_OWN_DW4 == 1 /* experiment: the step's own 16 bytes as four dword loads */
+#define CSNAPPY_ISA_OWN16 "global_load_dword v44, v49, %[src]\n\tglobal_load_dword v45, v49, %[src] offset:4\n\tglobal_load_dword v46, v49, %[src] offset:8\n\tglobal_load_dword v47, v49, %[src] offset:12\n\t"
+#elif CSNAPPY_OWN_DW4 == 2 /* ... as two 8-byte loads */
+#define CSNAPPY_ISA_OWN16 "global_load_dwordx2 v[44:45], v49, %[src]\n\tglobal_load_dwordx2 v[46:47], v49, %[src] offset:8\n\t"
+#else
+#define CSNAPPY_ISA_OWN16 "global_load_dwordx4 v[44:47], v49, %[src]\n\t"
+#endif
 #ifndef CSNAPPY_DENSE_WINDOW
 #define CSNAPPY_DENSE_WINDOW 0 /* 1: the dense loop takes its own bytes and ids out of a window requested a step ahead (A/B: no gain) */
 #endif
@@ -756,6 +768,11 @@ __device__ unsigned long long g_isa_prof[16];
 
 /* the pieces that differ between the table placements: the FRONT's table access (label 12), the test for
  * another round, the next step's loads and the commit (behind label 11) */
+#if CSNAPPY_TIMING_TA == 7 /* timing experiment: one more LDS read per step, nobody waits for it */
+#define CSNAPPY_TIMING_EXTRA_LDS "ds_read_b32 v60, v37\n\t"
+#else
+#define CSNAPPY_TIMING_EXTRA_LDS ""
+#endif
 #if CSNAPPY_TIMING_TA == 5 /* timing experiment (wrong output where compiled steps mix in): no check bit, every lane with a bucket gathers */
 #define CSNAPPY_ISA_DENSE_CHECK_BIT "v_mov_b32_e32 v59, 0\n\t"
 #elif CSNAPPY_TIMING_TA == 6 /* ... the check bit kept, its multiply paid twice */
@@ -788,6 +805,7 @@ __device__ unsigned long long g_isa_prof[16];
 	"global_store_dwordx2 v43, v[50:51], %[R]" CSNAPPY_NT_REC "\n\t" /* the previous step's records, behind the gather */ \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
 	CSNAPPY_ISA_P("v66")                                                                                               \
+	CSNAPPY_TIMING_EXTRA_LDS                                                                                           \
 	"v_bfe_u32 v57, v57, v58, 16\n\t"                  /* my half as the add found it */                               \
 	"v_cmp_ne_u32_e32 vcc, v57, v56\n\t"               /* not the entry: a lower lane has my slot */                   \
 	"s_and_b64 s[62:63], vcc, s[60:61]\n\t"            /* flagged lanes */                                             \
@@ -890,10 +908,11 @@ __device__ unsigned long long g_isa_prof[16];
 	"v_add_u32_e32 v40, %[p0], %[lane]\n\t"            /* the next step's positions */                                 \
 	"v_min_u32_e32 v49, %[safemax], v40\n\t"           /* (clamped: harmless loads when the loop ends here) */         \
 	CSNAPPY_TIMING_ROUND_TRIP                                                                      \
-	"global_load_dwordx4 v[44:47], v49, %[src]\n\t"                                                                    \
+	CSNAPPY_ISA_OWN16                                                                              \
 	CSNAPPY_TIMING_EXTRA_LOAD                                                                      \
 	"v_lshlrev_b32_e32 v48, 1, v49\n\t"                                                                                \
-	"global_load_ushort v42, v48, %[ids]" CSNAPPY_NT_IDL "\n\t"
+	"global_load_ushort v42, v48, %[ids]" CSNAPPY_NT_IDL "\n\t"                                                        \
+	CSNAPPY_TIMING_EXTRA_SMALL_LOAD
 
 #endif
 #define CSNAPPY_ISA_COMMIT_DENSE CSNAPPY_ISA_DENSE_OWN_FINISH CSNAPPY_ISA_COMMIT_LDS
